@@ -1,0 +1,265 @@
+/*
+ * raytracing_amd.h -- C ABI of the MI355X (gfx950) path-tracing library.
+ *
+ * The reference program (huris/RayTracing) has no plugin or FFI layer: each book is one
+ * translation unit whose main() builds a `hittable_list`, a `camera`, and then runs the
+ * sample loop -> ray_color() -> hittable::hit / material::scatter.  This header puts a C
+ * boundary at exactly that seam.  The caller (a reference-shaped C++ scene builder, or a
+ * ctypes/cgo/JNI stub) hands over
+ *   - the scene as plain arrays that mirror the reference's object graph one-to-one,
+ *   - the camera as the vectors the reference's camera constructor computes,
+ *   - the loop bounds of the reference's render loop,
+ * and receives the per-pixel colour SUM the reference hands to write_color().
+ *
+ * Everything crossing the boundary is a POD struct, a plain pointer or a size.  All
+ * geometry is IEEE double, like the reference ("Ray Tracing In a Weekend/code/vec3.h":63).
+ *
+ * Reference citations use B1 = "Ray Tracing In a Weekend/code", B2 = "Ray Tracing The Next
+ * Week/code" (B3, "The Rest Of Your Life/code", is a byte-identical copy of B2).
+ */
+#ifndef RAYTRACING_AMD_H
+#define RAYTRACING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ error codes */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1,   /* null pointer, bad size, bad index in a scene array   */
+    RT_ERR_UNSUPPORTED_SCENE = 2,  /* scene graph uses a construct no kernel covers (yet)  */
+    RT_ERR_NO_DEVICE = 3,          /* no gfx950 device visible / bad device ordinal        */
+    RT_ERR_HIP = 4,                /* a HIP runtime call failed (see rt_last_error_detail) */
+    RT_ERR_NO_SCENE = 5,           /* render / first-hit called before rt_scene_upload     */
+    RT_ERR_OUT_OF_MEMORY = 6,
+    RT_ERR_LIMIT = 7               /* a documented size limit was exceeded                 */
+};
+
+/* ------------------------------------------------------------------ scene graph
+ * One rt_node per reference `hittable` object.  `kind` names the reference class; `p[]`
+ * holds that class's public data members in declaration order (documented per kind).   */
+enum {
+    RT_NODE_SPHERE = 1,        /* B1/sphere.h:9-21      p[0..2]=center p[3]=radius (may be <0)        */
+    RT_NODE_MOVING_SPHERE = 2, /* B2/moving_sphere.h:8-25 p[0..2]=center0 p[3..5]=center1
+                                                         p[6]=time0 p[7]=time1 p[8]=radius            */
+    RT_NODE_XY_RECT = 3,       /* B2/aarect.h:7-26      p[0]=x0 p[1]=x1 p[2]=y0 p[3]=y1 p[4]=k        */
+    RT_NODE_XZ_RECT = 4,       /* B2/aarect.h:49-68     p[0]=x0 p[1]=x1 p[2]=z0 p[3]=z1 p[4]=k        */
+    RT_NODE_YZ_RECT = 5,       /* B2/aarect.h:91-110    p[0]=y0 p[1]=y1 p[2]=z0 p[3]=z1 p[4]=k        */
+    RT_NODE_BOX = 6,           /* B2/box.h:9-25         p[0..2]=box_min p[3..5]=box_max;
+                                                         children[child0 .. child0+child1) = 6 sides  */
+    RT_NODE_LIST = 7,          /* B1/hittable_list.h:12-24  children[child0 .. child0+child1)          */
+    RT_NODE_BVH = 8,           /* B2/bvh.h:10-27        child0=left child1=right p[0..2]=box.min
+                                                         p[3..5]=box.max                               */
+    RT_NODE_TRANSLATE = 9,     /* B2/hittable.h:31-41   child0=ptr p[0..2]=offset                     */
+    RT_NODE_ROTATE_Y = 10,     /* B2/hittable.h:62-79   child0=ptr p[0]=sin_theta p[1]=cos_theta
+                                                         p[2]=hasbox p[3..5]=bbox.min p[6..8]=bbox.max */
+    RT_NODE_MEDIUM = 11        /* B2/constant_medium.h:10-28 child0=boundary p[0]=neg_inv_density,
+                                                         material = the isotropic phase function       */
+};
+
+typedef struct rt_node {
+    int32_t kind;
+    int32_t material; /* index into materials[], -1 for containers                          */
+    int32_t child0;
+    int32_t child1;
+    double p[12];
+} rt_node;
+
+enum {
+    RT_MAT_LAMBERTIAN = 1,    /* B1/material.h:15-34, B2/material.h:20-40  texture = albedo  */
+    RT_MAT_METAL = 2,         /* B1/material.h:36-52   albedo[3], param = fuzz (already <=1)  */
+    RT_MAT_DIELECTRIC = 3,    /* B1/material.h:54-89   param = ir                              */
+    RT_MAT_DIFFUSE_LIGHT = 4, /* B2/material.h:97-114  texture = emit                          */
+    RT_MAT_ISOTROPIC = 5      /* B2/material.h:116-131 texture = albedo                        */
+};
+
+typedef struct rt_material {
+    int32_t kind;
+    int32_t texture; /* index into textures[] or -1 */
+    double albedo[3];
+    double param;
+} rt_material;
+
+enum {
+    RT_TEX_SOLID = 1,   /* B2/texture.h:15-28  p[0..2] = color_value                           */
+    RT_TEX_CHECKER = 2, /* B2/texture.h:30-46  a = even texture, b = odd texture                */
+    RT_TEX_NOISE = 3,   /* B2/texture.h:48-60  a = index into perlins[], p[0] = scale           */
+    RT_TEX_IMAGE = 4    /* B2/texture.h:62-110 a = index into images[], -1 = no data (cyan)     */
+};
+
+typedef struct rt_texture {
+    int32_t kind;
+    int32_t a;
+    int32_t b;
+    int32_t reserved;
+    double p[4];
+} rt_texture;
+
+/* B2/perlin.h:63-68: the four tables a `perlin` object rolls in its constructor. */
+typedef struct rt_perlin {
+    double ranvec[256][3];
+    int32_t perm_x[256];
+    int32_t perm_y[256];
+    int32_t perm_z[256];
+} rt_perlin;
+
+/* Decoded RGB8 image, rows top to bottom, as stbi_load(…, 3) returns it (B2/texture.h:71). */
+typedef struct rt_image {
+    int32_t width;
+    int32_t height;
+    const uint8_t* rgb;
+} rt_image;
+
+enum {
+    RT_SKY_GRADIENT = 0,  /* B1/RayTracing.cpp:28-30: white -> (0.5,0.7,1.0) by unit dir y    */
+    RT_SKY_BACKGROUND = 1 /* B2/RayTracing.cpp:25-26: constant `background` colour             */
+};
+
+typedef struct rt_scene_desc {
+    int32_t abi_version; /* RT_ABI_VERSION */
+    int32_t root;        /* index of the world node (a RT_NODE_LIST in every reference scene) */
+    int32_t n_nodes;
+    int32_t n_children;
+    int32_t n_materials;
+    int32_t n_textures;
+    int32_t n_perlins;
+    int32_t n_images;
+    const rt_node* nodes;
+    const int32_t* children; /* child index lists of LIST / BOX nodes */
+    const rt_material* materials;
+    const rt_texture* textures;
+    const rt_perlin* perlins;
+    const rt_image* images;
+    int32_t sky_mode;
+    int32_t reserved;
+    double background[3];
+} rt_scene_desc;
+
+/* The private members of the reference camera after its constructor has run
+ * (B1/camera.h:41-47, B2/camera.h:47-54).  rt_camera_init() computes them on the host
+ * exactly as the constructor does.                                                      */
+typedef struct rt_camera_desc {
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double w[3];
+    double lens_radius;
+    double time0;
+    double time1;
+} rt_camera_desc;
+
+/* Loop bounds of the reference render loop (B1/RayTracing.cpp:82-86,115-127).
+ * Samples of a pixel are numbered globally 0..spp-1; a call renders the half-open range
+ * [sample_begin, sample_begin + sample_count) of every pixel, so that a frame split over
+ * several GPUs (or several calls) draws exactly the random numbers of the unsplit frame. */
+typedef struct rt_render_params {
+    int32_t width;
+    int32_t height;
+    int32_t sample_begin;
+    int32_t sample_count;
+    int32_t max_depth;
+    int32_t flags; /* RT_RENDER_* */
+    uint64_t seed; /* Philox key */
+} rt_render_params;
+
+enum {
+    RT_RENDER_DEFAULT = 0,
+    RT_RENDER_EXACT_ONLY = 1 /* validation: skip the float screening pass, test every object in double */
+};
+
+/* Colour sums are accumulated in 64-bit fixed point so that the sum over samples does not
+ * depend on the order in which lanes, waves or GPUs add them: value = fixed * 2^-RT_ACCUM_FRAC_BITS. */
+#define RT_ACCUM_FRAC_BITS 36
+
+typedef struct rt_stats {
+    uint64_t samples;       /* camera rays started                                   */
+    uint64_t rays;          /* world.hit() calls (ray segments), as the reference counts them */
+    uint64_t nan_samples;   /* samples whose colour was NaN/Inf and was dropped      */
+    uint64_t overflow_rays; /* rays that took the slow exact path (candidate list full) */
+    double kernel_ms;       /* device time of the render kernel(s), HIP events        */
+} rt_stats;
+
+typedef struct rt_context rt_context;
+
+/* ------------------------------------------------------------------ entry points */
+
+/* Number of HIP devices visible to this process (0 if none; never fails). */
+int rt_get_device_count(void);
+
+/* Create a context bound to one device.  One process per GPU is the intended use; a
+ * context is used from one host thread at a time.  `stream` may be NULL (the library then
+ * creates its own stream) or an existing hipStream_t on that device passed as void*.    */
+int rt_context_create(int device_ordinal, void* stream, rt_context** out);
+void rt_context_destroy(rt_context* ctx);
+
+/* Copy the scene to the device (replaces any earlier scene of this context).  The caller
+ * keeps ownership of every host array; nothing is referenced after the call returns.
+ * Stands in for the world handed to ray_color (B1/RayTracing.cpp:90, B2/RayTracing.cpp:271-351). */
+int rt_scene_upload(rt_context* ctx, const rt_scene_desc* scene);
+
+/* The reference sample loop + ray_color (B1/RayTracing.cpp:11-31,115-127;
+ * B2/RayTracing.cpp:17-36,365-377).  Adds the colour of samples
+ * [sample_begin, sample_begin+sample_count) of every pixel and writes the sums, as doubles,
+ * to the HOST array accum_rgb_out[3*width*height] (row 0 = top image row, i.e. the
+ * reference's j = height-1; channel order r,g,b).  Synchronous.  stats may be NULL.     */
+int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,
+              double* accum_rgb_out, rt_stats* stats);
+
+/* Same work, but the result stays on the device as 64-bit fixed point (see
+ * RT_ACCUM_FRAC_BITS) in the caller's DEVICE buffer d_accum_fixed[3*width*height]
+ * (e.g. a torch int64 tensor), which the call ADDS to: zero it before the first call of a
+ * frame.  The kernel is enqueued on the context's stream and the call returns without
+ * waiting; rt_context_synchronize() waits.  This is the entry point a multi-GPU caller
+ * uses before summing the buffers of all ranks with an all-reduce.                      */
+int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,
+                     int64_t* d_accum_fixed);
+int rt_context_synchronize(rt_context* ctx);
+/* Validation switch: when on, kernels skip their float screening pass and test every object
+ * in double.  Results must be identical either way; only the speed differs. */
+int rt_context_set_exact_only(rt_context* ctx, int on);
+/* Statistics of everything rendered since the last call of this function (synchronises). */
+int rt_context_take_stats(rt_context* ctx, rt_stats* out);
+
+/* Closest-hit object of the ray through each pixel CENTRE, s=(i+0.5)/(width-1),
+ * t=(j+0.5)/(height-1), lens sample (0,0), shutter time time0: the index, within the root
+ * list, of the object whose hit the reference's hittable_list::hit would keep
+ * (B1/hittable_list.h:26-39, t_min = 0.001, later object wins exact ties), or -1 for a
+ * miss.  ids_out is a HOST array of width*height int32, row 0 = top row.  Computed in
+ * double with the reference's operation order; meant to be compared bit for bit.        */
+int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int height,
+                 int32_t* ids_out);
+
+/* Host helpers that restate small host-side pieces of the reference. */
+
+/* camera::camera (B1/camera.h:8-32, B2/camera.h:8-36). */
+void rt_camera_init(rt_camera_desc* out, const double lookfrom[3], const double lookat[3],
+                    const double vup[3], double vfov_degrees, double aspect_ratio, double aperture,
+                    double focus_dist, double time0, double time1);
+
+/* write_color (B1/color.h:8-23) for a whole image: sums -> 8-bit gamma-2 rgb[3*w*h].
+ * A NaN sum maps to 0 (the reference prints INT_MIN there). */
+void rt_write_color(const double* accum_rgb, int width, int height, int samples_per_pixel,
+                    uint8_t* rgb_out);
+
+/* The reference's P3 output stream (B1/RayTracing.cpp:113,125): "P3\nW H\n255\n" then one
+ * "r g b\n" line per pixel.  Returns RT_OK or RT_ERR_INVALID_ARGUMENT (file not writable). */
+int rt_write_ppm(const char* path, const uint8_t* rgb, int width, int height);
+
+const char* rt_error_string(int code);
+/* Human-readable detail of the last failure on this context (or of context creation when
+ * ctx is NULL).  The pointer stays valid until the next failing call.                   */
+const char* rt_last_error_detail(const rt_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACING_AMD_H */

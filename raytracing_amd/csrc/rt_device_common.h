@@ -1,0 +1,88 @@
+// Device-side building blocks shared by the gfx950 kernels: Philox4x32-10, the draw
+// convention, and small double-precision vector helpers that keep the reference's
+// operation order.  This translation unit family is compiled with -ffp-contract=off: every
+// double expression below rounds exactly as the reference's x86-64 build does; fused
+// multiply-adds appear only where written explicitly (the float screening pass).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raytracing_amd.h"
+
+namespace rtd {
+
+// ---------------------------------------------------------------- random numbers
+// One Philox4x32-10 block (Salmon et al., SC'11; Random123 constants) per
+// (pixel, sample, site, try); key = the 64-bit seed.
+//   site 0       camera ray of the sample: try 0 = [jitter u, jitter v, lens x, lens y],
+//                try k>0 = [lens x, lens y, -, -] (k-th retry of the unit-disk rejection loop,
+//                B1/vec3.h:145-151), try TRY_TIME = [shutter time, -, -, -]
+//   site 1+b     ray segment b: try k = [x, y, z, -] of the k-th unit-sphere rejection attempt
+//                (B1/vec3.h:114-120) or [Schlick draw, -, -, -] for a dielectric
+//                (B1/material.h:72); try TRY_MEDIUM+m = the m-th constant_medium draw
+//                (B2/constant_medium.h:48) met while intersecting the segment.
+// A draw is (word >> 1) * 2^-31: the 31-bit grid of rand()/(RAND_MAX+1.0) (B1/rtweekend.h:24-27).
+constexpr uint32_t TRY_TIME = 0x80000000u;
+constexpr uint32_t TRY_MEDIUM = 0x40000000u;
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double u01(uint32_t word) { return (double)(word >> 1) * 4.656612873077392578125e-10; }
+// random_double(MIN, MAX), B1/rtweekend.h:37-40
+__device__ __forceinline__ double u_range(uint32_t word, double lo, double hi) { return lo + (hi - lo) * u01(word); }
+
+// ---------------------------------------------------------------- vec3 (B1/vec3.h)
+struct d3 {
+    double x, y, z;
+};
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ d3 operator*(double t, d3 a) { return d3{t * a.x, t * a.y, t * a.z}; }
+__device__ __forceinline__ d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double len2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// operator/(vec3, double) multiplies by the reciprocal (B1/vec3.h:96-98)
+__device__ __forceinline__ d3 div_by(d3 a, double t) { return (1 / t) * a; }
+__device__ __forceinline__ d3 unit_vector(d3 a) { return div_by(a, sqrt(len2(a))); }
+__device__ __forceinline__ d3 reflect(d3 v, d3 n) { return v - (2 * dot(v, n)) * n; }  // B1/vec3.h:134-136
+__device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {            // B1/vec3.h:138-143
+    const double cos_theta = fmin(dot(-uv, n), 1.0);
+    const d3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    const d3 r_out_parallel = (-sqrt(fabs(1.0 - len2(r_out_perp)))) * n;
+    return r_out_perp + r_out_parallel;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// number of set bits of `m` below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+constexpr double ACCUM_SCALE = (double)(1ull << RT_ACCUM_FRAC_BITS);
+
+}  // namespace rtd

@@ -1,0 +1,79 @@
+// Internal interface between the C-ABI host layer (rt_api.hip) and the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "raytracing_amd.h"
+
+namespace rtd {
+
+// ---- device layout of a flat list of spheres (book-1 worlds: B1/hittable_list.h + B1/sphere.h)
+//
+// Two images of every sphere live in HBM (a 487-sphere world is 7.8 KB + 15.6 KB, so both
+// stay in the scalar / vector caches for the whole render):
+//  - SphereScreen, 16 B, float: read with wave-uniform scalar loads by the screening pass;
+//  - SphereExact, 32 B, double: gathered per lane by the exact pass for the few candidates.
+struct SphereScreen {
+    float cx, cy, cz;
+    float k;  // |c|^2 - r^2 - margin(c, r), rounded from double; see screen pass
+};
+struct SphereExact {
+    double cx, cy, cz, radius;
+};
+struct MaterialDev {
+    int32_t kind;  // RT_MAT_*
+    int32_t pad;
+    double ax, ay, az;  // albedo (lambertian with a solid texture, metal)
+    double param;       // fuzz / ir
+};
+
+constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word
+constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
+
+struct SphereListDev {
+    int32_t n;         // spheres in list order (= object ids)
+    int32_t n_groups;  // ceil(n / SCREEN_GROUP); the screen image is padded to a full group
+    const SphereScreen* screen;
+    const SphereExact* exact;
+    const int32_t* material_of;
+    const MaterialDev* materials;
+    int32_t sky_mode;
+    double background[3];
+};
+
+struct CameraDev {
+    double origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
+    double lens_radius, time0, time1;
+};
+
+struct RenderArgs {
+    SphereListDev scene;
+    CameraDev cam;
+    int32_t width, height;
+    int32_t sample_begin, sample_count;
+    int32_t max_depth;
+    int32_t chunk;          // samples of one pixel that form a work item
+    uint32_t n_items;       // number of work items
+    uint32_t key0, key1;    // Philox key
+    int32_t exact_only;     // 1: skip the float screen, test every sphere in double (validation)
+    int64_t* accum;         // [3*width*height] fixed point, added to with atomics
+    uint32_t* item_counter; // work-queue head, zeroed before launch
+    uint64_t* stats;        // [4]: samples, rays, non-finite samples, overflow rays
+};
+
+struct FirstHitArgs {
+    SphereListDev scene;
+    CameraDev cam;
+    int32_t width, height;
+    int32_t exact_only;
+    int32_t* ids;
+};
+
+// Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.
+hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_first_hit_spheres(const FirstHitArgs& args, hipStream_t stream);
+// Resident 256-thread workgroups per CU of the render kernel, as the runtime reports it.
+int render_spheres_blocks_per_cu();
+
+}  // namespace rtd

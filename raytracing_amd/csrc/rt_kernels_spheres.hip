@@ -1,0 +1,421 @@
+// gfx950 kernels for worlds that are a flat list of spheres (book 1: configs 1 and 2).
+//
+// Replaces, for every pixel and sample, the reference's render loop body
+//   B1/RayTracing.cpp:119-124  jitter -> camera::get_ray -> ray_color
+//   B1/RayTracing.cpp:11-31    ray_color (recursion unrolled into a per-lane loop)
+//   B1/hittable_list.h:26-39   closest hit over all objects
+//   B1/sphere.h:23-50          sphere::hit
+//   B1/material.h:19-77        lambertian / metal / dielectric scatter
+//
+// Structure of one wave (64 lanes, one path per lane):
+//   refill   lanes whose path ended take the next sample of their work item (a run of
+//            `chunk` samples of one pixel) or a new item from a device-wide queue, and
+//            build the camera ray.  Colour sums stay in registers as 64-bit fixed point
+//            and are added to HBM once per item, so the result does not depend on which
+//            lane or wave (or GPU) rendered which sample.
+//   screen   ALL lanes walk ALL spheres together: the sphere image is read with
+//            wave-uniform scalar loads (SGPR operands, no vector memory traffic) and each
+//            lane evaluates a conservative float discriminant in 9 VALU ops per sphere,
+//            shifting the sign bit into a 32-sphere mask word.
+//   exact    each lane re-tests only its own candidates in double with the reference's
+//            operation order, in list order and with the reference's closest-so-far
+//            rule, so the winner and its t are those of the reference bit for bit.
+//   shade    the reference's scatter functions in double; random numbers from Philox.
+//
+// The float screen can only add candidates, never drop a true hit (bound in screen_prepare),
+// so the rendered numbers are those of an all-double renderer.
+#include "rt_device_common.h"
+#include "rt_internal.h"
+
+namespace rtd {
+
+// ---------------------------------------------------------------- screening pass
+//
+// For a ray o + t*d (d normalised to d^) and a sphere (c, r), real roots exist iff
+//     D = (oc.d^)^2 - |oc|^2 + r^2 >= 0,      oc = o - c.
+// Expanded so that each VALU op has exactly one per-sphere (scalar) operand:
+//     hb  = o.d^ - c.d^                                   3 fma
+//     acc = (m_o - |o|^2) - k + 2 o.c                     1 sub + 3 fma,  k = |c|^2 - r^2 - m_c
+//     q   = hb^2 + acc  = D + m_o + m_c                   1 fma
+// Every intermediate is bounded by (|o|+|c|)^2 + r^2, and with eps = 2^-24 the rounding of
+// the float inputs (o, d^, c, k) plus the 8 operations perturbs q by less than
+// 28 eps ((|o|+|c|)^2 + r^2) <= 56 eps (|o|^2 + |c|^2) + 28 eps r^2.  The margins
+//     m_o = 2^-18 |o|^2,   m_c = 2^-18 (|c|^2 + r^2)        (2^-18 = 64 eps)
+// exceed that, so a sphere whose reference discriminant (a double, relative error 1e-15)
+// is >= 0 always yields q > 0.  The sign bit of q is shifted into the mask: 0 = candidate.
+struct ScreenRay {
+    float dx, dy, dz;     // d^
+    float p2ox, p2oy, p2oz;  // 2 o
+    float od;             // o . d^
+    float e;              // m_o - |o|^2
+};
+
+__device__ __forceinline__ ScreenRay screen_prepare(d3 o, d3 d, double a /* |d|^2 */) {
+    const double inv_len = 1.0 / sqrt(a);
+    const d3 dh = inv_len * d;
+    const double oo = len2(o);
+    ScreenRay s;
+    s.dx = (float)dh.x;
+    s.dy = (float)dh.y;
+    s.dz = (float)dh.z;
+    s.p2ox = (float)(2.0 * o.x);
+    s.p2oy = (float)(2.0 * o.y);
+    s.p2oz = (float)(2.0 * o.z);
+    s.od = (float)dot(o, dh);
+    s.e = (float)(oo * (0x1p-18 - 1.0));
+    return s;
+}
+
+typedef __attribute__((address_space(4))) SphereScreen ConstSphereScreen;
+
+__device__ __forceinline__ uint32_t screen_one(const ScreenRay& r, const SphereScreen s, uint32_t mask) {
+    float hb = __builtin_fmaf(-s.cx, r.dx, r.od);
+    hb = __builtin_fmaf(-s.cy, r.dy, hb);
+    hb = __builtin_fmaf(-s.cz, r.dz, hb);
+    float acc = r.e - s.k;
+    acc = __builtin_fmaf(r.p2ox, s.cx, acc);
+    acc = __builtin_fmaf(r.p2oy, s.cy, acc);
+    acc = __builtin_fmaf(r.p2oz, s.cz, acc);
+    const float q = __builtin_fmaf(hb, hb, acc);
+    return __builtin_amdgcn_alignbit(mask, __float_as_uint(q), 31);
+}
+
+// ---------------------------------------------------------------- exact pass
+struct Hit {
+    double t;
+    int32_t id;
+};
+
+// sphere::hit up to the accepted root, B1/sphere.h:24-41, inside the closest-so-far loop of
+// hittable_list::hit, B1/hittable_list.h:31-37.  Comparisons keep the reference's form so
+// that NaNs fall the same way.
+__device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d3 d, double a, double t_min, Hit& h) {
+    const SphereExact e = S.exact[j];
+    const d3 oc = o - d3{e.cx, e.cy, e.cz};
+    const double half_b = dot(oc, d);
+    const double c = len2(oc) - e.radius * e.radius;
+    const double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return;
+    const double sqrtd = sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || root > h.t) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || root > h.t) return;
+    }
+    h.t = root;
+    h.id = j;
+}
+
+// Closest hit of one ray per lane against the whole list.  Must be called by all 64 lanes
+// of the wave (wave-level loops); lanes with on == false take no part in the result.
+// `list` = this wave's CAND_CAP*64 uint16 slots in LDS.
+__device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, bool on, bool exact_only,
+                                           uint16_t* list, int lane, uint32_t& overflow_count) {
+    const double a = len2(d);
+    const double t_min = 0.001;  // B1/RayTracing.cpp:17
+    Hit h{__builtin_inf(), -1};
+
+    if (exact_only) {
+        if (on) {
+            for (int j = 0; j < S.n; ++j) exact_one(S, j, o, d, a, t_min, h);
+        }
+        return h;
+    }
+
+    const ScreenRay sr = screen_prepare(o, d, a);
+    uint32_t cnt = 0;
+    for (int g = 0; g < S.n_groups; ++g) {
+        // The screen image is immutable for the whole launch: address it through the constant
+        // address space so that the wave-uniform reads become scalar loads (SGPR operands).
+        const ConstSphereScreen* sp = (const ConstSphereScreen*)(S.screen + g * SCREEN_GROUP);
+        uint32_t mask = 0;
+#pragma unroll
+        for (int jj = 0; jj < SCREEN_GROUP; ++jj) mask = screen_one(sr, sp[jj], mask);
+        uint32_t cand = on ? ~mask : 0u;
+        while (ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int z = __clz((int)cand);
+                cand &= ~(0x80000000u >> z);
+                if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)(g * SCREEN_GROUP + z);
+                ++cnt;
+            }
+        }
+    }
+
+    const bool overflow = cnt > (uint32_t)CAND_CAP;
+    const uint32_t my_n = overflow ? 0u : cnt;
+    for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
+        if (i < my_n) exact_one(S, (int)list[i * 64 + lane], o, d, a, t_min, h);
+    }
+    if (ballot(overflow) != 0ull) {
+        if (overflow) {  // more candidates than slots: test the whole list in double
+            ++overflow_count;
+            for (int j = 0; j < S.n; ++j) exact_one(S, j, o, d, a, t_min, h);
+        }
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------- camera
+// camera::get_ray (B1/camera.h:34-39) for pixel column i, reference row j, sample `sample`.
+__device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int i, int j, uint32_t pixel,
+                                           uint32_t sample, uint32_t k0, uint32_t k1, d3& o, d3& d) {
+    u32x4 w = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
+    const double s = (i + u01(w.x)) / (W - 1);  // B1/RayTracing.cpp:120-121
+    const double t = (j + u01(w.y)) / (H - 1);
+    double px = u_range(w.z, -1, 1), py = u_range(w.w, -1, 1);
+    for (uint32_t k = 1; px * px + py * py + 0.0 * 0.0 >= 1; ++k) {  // random_in_unit_disk
+        w = philox4x32_10(pixel, sample, 0u, k, k0, k1);
+        px = u_range(w.x, -1, 1);
+        py = u_range(w.y, -1, 1);
+    }
+    const double rdx = C.lens_radius * px, rdy = C.lens_radius * py;
+    const d3 cu{C.u[0], C.u[1], C.u[2]}, cv{C.v[0], C.v[1], C.v[2]};
+    const d3 offset = rdx * cu + rdy * cv;
+    const d3 origin{C.origin[0], C.origin[1], C.origin[2]};
+    const d3 llc{C.llc[0], C.llc[1], C.llc[2]};
+    const d3 hor{C.horizontal[0], C.horizontal[1], C.horizontal[2]};
+    const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
+    o = origin + offset;
+    d = llc + s * hor + t * ver - origin - offset;
+}
+
+// random_in_unit_sphere, B1/vec3.h:114-120, for the lanes with need == true.
+__device__ __forceinline__ d3 random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t site,
+                                                    uint32_t k0, uint32_t k1) {
+    d3 p{0, 0, 0};
+    for (uint32_t k = 0; need; ++k) {
+        const u32x4 w = philox4x32_10(pixel, sample, site, k, k0, k1);
+        p = d3{u_range(w.x, -1, 1), u_range(w.y, -1, 1), u_range(w.z, -1, 1)};
+        if (!(len2(p) >= 1)) need = false;
+    }
+    return p;
+}
+
+__device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  // B1/material.h:83-88
+    double r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    const double x = 1 - cosine;
+    const double x2 = x * x;
+    return r0 + (1 - r0) * (x2 * x2 * x);  // pow(x, 5) by multiplication (<= 2 ulp from libm pow)
+}
+
+__device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
+    __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------- render kernel
+__global__ void __launch_bounds__(256) k_render_spheres(const RenderArgs A) {
+    __shared__ uint16_t s_list[4][CAND_CAP * 64];
+    const int lane = threadIdx.x & 63;
+    uint16_t* list = s_list[threadIdx.x >> 6];
+    const SphereListDev& S = A.scene;
+    const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
+    const int s_last = A.sample_begin + A.sample_count;
+
+    // per-lane path state
+    bool active = false, has_item = false, retired = false;
+    uint32_t pixel = 0, bounce = 0;
+    int s_cur = 0, s_end = 0, depth_left = 0;
+    int64_t fx = 0, fy = 0, fz = 0;
+    d3 o{0, 0, 0}, d{0, 0, 1}, T{1, 1, 1};
+    // wave-uniform work-queue window
+    uint32_t batch_next = 0, batch_end = 0;
+    bool queue_empty = false;
+    uint32_t n_samples = 0, n_rays = 0, n_bad = 0, n_overflow = 0;
+
+    for (;;) {
+        // ---- refill: finish items, take new ones, start the next sample
+        if (!active && has_item && s_cur == s_end) {
+            atomic_add_i64(A.accum + 3ull * pixel + 0, fx);
+            atomic_add_i64(A.accum + 3ull * pixel + 1, fy);
+            atomic_add_i64(A.accum + 3ull * pixel + 2, fz);
+            has_item = false;
+        }
+        bool need = !active && !retired && !has_item;
+        while (ballot(need) != 0ull) {
+            if (batch_next == batch_end) {
+                if (!queue_empty) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(A.item_counter, 64u);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base >= A.n_items) {
+                        queue_empty = true;
+                    } else {
+                        batch_next = base;
+                        batch_end = min(base + 64u, A.n_items);
+                    }
+                }
+                if (queue_empty) {
+                    if (need) retired = true;
+                    need = false;
+                    break;
+                }
+            }
+            const uint64_t m = ballot(need);
+            const uint32_t rank = rank_below(m);
+            const uint32_t avail = batch_end - batch_next;
+            if (need && rank < avail) {
+                const uint32_t item = batch_next + rank;
+                pixel = item % npix;
+                const int chunk_idx = (int)(item / npix);
+                s_cur = A.sample_begin + chunk_idx * A.chunk;
+                s_end = min(s_cur + A.chunk, s_last);
+                fx = fy = fz = 0;
+                has_item = true;
+                need = false;
+            }
+            batch_next += min((uint32_t)__popcll(m), avail);
+        }
+        if (ballot(!retired) == 0ull) break;
+
+        if (!active && has_item) {
+            const int i = (int)(pixel % (uint32_t)A.width);
+            const int j = A.height - 1 - (int)(pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
+            camera_ray(A.cam, A.width, A.height, i, j, pixel, (uint32_t)s_cur, A.key0, A.key1, o, d);
+            T = d3{1, 1, 1};
+            depth_left = A.max_depth;
+            bounce = 0;
+            active = true;
+            ++n_samples;
+        }
+
+        // ---- closest hit (all lanes together)
+        const bool on = active;
+        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, lane, n_overflow);
+
+        // ---- shade
+        if (on) {
+            ++n_rays;
+            const uint32_t sample = (uint32_t)s_cur;
+            const uint32_t site = 1u + bounce;
+            bool done = false;
+            d3 L_end{0, 0, 0};
+            if (h.id < 0) {
+                if (S.sky_mode == RT_SKY_GRADIENT) {  // B1/RayTracing.cpp:28-30
+                    const d3 unit_direction = unit_vector(d);
+                    const double t = 0.5 * (unit_direction.y + 1.0);
+                    L_end = (1.0 - t) * d3{1.0, 1.0, 1.0} + t * d3{0.5, 0.7, 1.0};
+                } else {
+                    L_end = d3{S.background[0], S.background[1], S.background[2]};
+                }
+                done = true;
+            } else {
+                // rest of sphere::hit, B1/sphere.h:43-47
+                const SphereExact e = S.exact[h.id];
+                const d3 p = o + h.t * d;
+                const d3 outward_normal = div_by(p - d3{e.cx, e.cy, e.cz}, e.radius);
+                const bool front_face = dot(d, outward_normal) < 0;
+                const d3 normal = front_face ? outward_normal : -outward_normal;
+                const MaterialDev m = S.materials[S.material_of[h.id]];
+                d3 attenuation{m.ax, m.ay, m.az};
+                d3 nd{0, 0, 0};
+                const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL;
+                const d3 rs = random_in_unit_sphere(wants_sphere, pixel, sample, site, A.key0, A.key1);
+                if (m.kind == RT_MAT_LAMBERTIAN) {  // B1/material.h:19-30
+                    nd = normal + unit_vector(rs);
+                    const double s = 1e-8;
+                    if ((fabs(nd.x) < s) && (fabs(nd.y) < s) && (fabs(nd.z) < s)) nd = normal;
+                } else if (m.kind == RT_MAT_METAL) {  // B1/material.h:40-47
+                    const d3 reflected = reflect(unit_vector(d), normal);
+                    nd = reflected + m.param * rs;
+                    if (!(dot(nd, normal) > 0)) done = true;  // absorbed: black
+                } else {  // dielectric, B1/material.h:58-77
+                    attenuation = d3{1.0, 1.0, 1.0};
+                    const double refraction_ratio = front_face ? (1.0 / m.param) : m.param;
+                    const d3 unit_direction = unit_vector(d);
+                    const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
+                    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                    bool do_reflect = refraction_ratio * sin_theta > 1.0;
+                    if (!do_reflect) {
+                        const u32x4 w = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);
+                        do_reflect = reflectance(cos_theta, refraction_ratio) > u01(w.x);
+                    }
+                    nd = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
+                }
+                if (!done) {
+                    T = T * attenuation;
+                    o = p;
+                    d = nd;
+                    ++bounce;
+                    if (--depth_left <= 0) done = true;  // B1/RayTracing.cpp:15: the next call returns black
+                }
+            }
+            if (done) {
+                const d3 c = T * L_end;
+                if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) {
+                    fx += __double2ll_rn(c.x * ACCUM_SCALE);
+                    fy += __double2ll_rn(c.y * ACCUM_SCALE);
+                    fz += __double2ll_rn(c.z * ACCUM_SCALE);
+                } else {
+                    ++n_bad;
+                }
+                active = false;
+                ++s_cur;
+            }
+        }
+    }
+
+    // ---- statistics: one atomic per counter per wave
+    uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad, v3 = n_overflow;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v0 += __shfl_xor(v0, off);
+        v1 += __shfl_xor(v1, off);
+        v2 += __shfl_xor(v2, off);
+        v3 += __shfl_xor(v3, off);
+    }
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&A.stats[0], (unsigned long long)v0);
+        atomicAdd((unsigned long long*)&A.stats[1], (unsigned long long)v1);
+        atomicAdd((unsigned long long*)&A.stats[2], (unsigned long long)v2);
+        atomicAdd((unsigned long long*)&A.stats[3], (unsigned long long)v3);
+    }
+}
+
+// ---------------------------------------------------------------- first-hit kernel
+// One lane per pixel centre; definition in raytracing_amd.h (rt_first_hit).
+__global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A) {
+    __shared__ uint16_t s_list[4][CAND_CAP * 64];
+    const int lane = threadIdx.x & 63;
+    uint16_t* list = s_list[threadIdx.x >> 6];
+    const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    const bool on = pixel < npix;
+    const uint32_t pc = on ? pixel : 0u;
+    const int i = (int)(pc % (uint32_t)A.width);
+    const int j = A.height - 1 - (int)(pc / (uint32_t)A.width);
+    const CameraDev& C = A.cam;
+    const double s = (i + 0.5) / (A.width - 1);
+    const double t = (j + 0.5) / (A.height - 1);
+    const d3 cu{C.u[0], C.u[1], C.u[2]}, cv{C.v[0], C.v[1], C.v[2]};
+    const d3 offset = 0.0 * cu + 0.0 * cv;
+    const d3 origin{C.origin[0], C.origin[1], C.origin[2]};
+    const d3 llc{C.llc[0], C.llc[1], C.llc[2]};
+    const d3 hor{C.horizontal[0], C.horizontal[1], C.horizontal[2]};
+    const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
+    const d3 o = origin + offset;
+    const d3 d = llc + s * hor + t * ver - origin - offset;
+    uint32_t ovf = 0;
+    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, lane, ovf);
+    if (on) A.ids[pixel] = h.id;
+}
+
+hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_render_spheres, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_first_hit_spheres(const FirstHitArgs& args, hipStream_t stream) {
+    const uint32_t npix = (uint32_t)args.width * (uint32_t)args.height;
+    hipLaunchKernelGGL(k_first_hit_spheres, dim3((npix + 255u) / 256u), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+int render_spheres_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres, 256, 0) != hipSuccess || n < 1) n = 2;
+    return n;
+}
+
+}  // namespace rtd

@@ -1,0 +1,173 @@
+"""ctypes binding of libraytracing_amd.so (the HIP library behind include/raytracing_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is visible when a
+context is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        super().__init__(f"{what}: error {code} ({detail})")
+        self.code = code
+
+
+def load():
+    """Load the HIP library (built in-tree by `make -C raytracing_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    ctx_p = C.c_void_p
+    L.rt_get_device_count.restype = C.c_int
+    L.rt_context_create.restype = C.c_int
+    L.rt_context_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(ctx_p)]
+    L.rt_context_destroy.restype = None
+    L.rt_context_destroy.argtypes = [ctx_p]
+    L.rt_scene_upload.restype = C.c_int
+    L.rt_scene_upload.argtypes = [ctx_p, C.POINTER(abi.rt_scene_desc)]
+    L.rt_render.restype = C.c_int
+    L.rt_render.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p,
+                            C.POINTER(abi.rt_stats)]
+    L.rt_render_device.restype = C.c_int
+    L.rt_render_device.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
+    L.rt_context_synchronize.restype = C.c_int
+    L.rt_context_synchronize.argtypes = [ctx_p]
+    L.rt_context_set_exact_only.restype = C.c_int
+    L.rt_context_set_exact_only.argtypes = [ctx_p, C.c_int]
+    L.rt_context_take_stats.restype = C.c_int
+    L.rt_context_take_stats.argtypes = [ctx_p, C.POINTER(abi.rt_stats)]
+    L.rt_first_hit.restype = C.c_int
+    L.rt_first_hit.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.c_int, C.c_int, C.c_void_p]
+    L.rt_camera_init.restype = None
+    L.rt_camera_init.argtypes = [C.POINTER(abi.rt_camera_desc), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double)] + [C.c_double] * 6
+    L.rt_write_color.restype = None
+    L.rt_write_color.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.rt_write_ppm.restype = C.c_int
+    L.rt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    L.rt_error_string.restype = C.c_char_p
+    L.rt_error_string.argtypes = [C.c_int]
+    L.rt_last_error_detail.restype = C.c_char_p
+    L.rt_last_error_detail.argtypes = [ctx_p]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "rt_get_device_count", "rt_context_create", "rt_context_destroy", "rt_scene_upload", "rt_render",
+    "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_take_stats",
+    "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
+]
+
+
+def camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus, time0=0.0, time1=0.0) -> abi.rt_camera_desc:
+    """camera::camera of the reference, computed on the host by the library."""
+    cam = abi.rt_camera_desc()
+    v = lambda a: (C.c_double * 3)(*[float(x) for x in a])
+    load().rt_camera_init(C.byref(cam), v(lookfrom), v(lookat), v(vup), vfov, aspect, aperture, focus, time0, time1)
+    return cam
+
+
+def write_color(accum, spp) -> np.ndarray:
+    H, W, _ = accum.shape
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    a = np.ascontiguousarray(accum, dtype=np.float64)
+    load().rt_write_color(a.ctypes.data, W, H, int(spp), out.ctypes.data)
+    return out
+
+
+def write_ppm(path, rgb) -> None:
+    H, W, _ = rgb.shape
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    rc = load().rt_write_ppm(os.fsencode(path), a.ctypes.data, W, H)
+    if rc != 0:
+        raise RtError(rc, "rt_write_ppm")
+
+
+def stats_dict(st: abi.rt_stats) -> dict:
+    return {"samples": int(st.samples), "rays": int(st.rays), "nan_samples": int(st.nan_samples),
+            "overflow_rays": int(st.overflow_rays), "kernel_ms": float(st.kernel_ms)}
+
+
+class Context:
+    """One GPU, one scene at a time; mirrors the rt_context_* entry points."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.rt_context_create(int(device), stream, C.byref(self._h))
+        if rc != 0:
+            raise RtError(rc, "rt_context_create", self._L.rt_last_error_detail(None).decode())
+        self._scene = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(rc, what, self._L.rt_last_error_detail(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.rt_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene: abi.Scene):
+        d = scene.desc()
+        self._check(self._L.rt_scene_upload(self._h, C.byref(d)), "rt_scene_upload")
+        self._scene = scene
+
+    def set_exact_only(self, on: bool):
+        self._check(self._L.rt_context_set_exact_only(self._h, int(bool(on))), "rt_context_set_exact_only")
+
+    def render(self, cam, params):
+        """-> (double colour sums [H,W,3], stats dict)"""
+        out = np.zeros((params.height, params.width, 3), dtype=np.float64)
+        st = abi.rt_stats()
+        self._check(self._L.rt_render(self._h, C.byref(cam), C.byref(params), out.ctypes.data, C.byref(st)),
+                    "rt_render")
+        return out, stats_dict(st)
+
+    def render_device(self, cam, params, d_accum_ptr: int):
+        """Enqueue a render that ADDS fixed-point sums into device memory at `d_accum_ptr`."""
+        self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_accum_ptr)),
+                    "rt_render_device")
+
+    def synchronize(self):
+        self._check(self._L.rt_context_synchronize(self._h), "rt_context_synchronize")
+
+    def take_stats(self) -> dict:
+        st = abi.rt_stats()
+        self._check(self._L.rt_context_take_stats(self._h, C.byref(st)), "rt_context_take_stats")
+        return stats_dict(st)
+
+    def first_hit(self, cam, width, height) -> np.ndarray:
+        ids = np.zeros((height, width), dtype=np.int32)
+        self._check(self._L.rt_first_hit(self._h, C.byref(cam), int(width), int(height), ids.ctypes.data),
+                    "rt_first_hit")
+        return ids
