@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s on the One-Weekend final scene (BASELINE.json configs[1]).
+
+A step is one full frame of the reference's render loop over the dumped 487-sphere world:
+1200x800 pixels, 500 samples per pixel, depth 50, camera of RayTracing.cpp:104-110.  With N
+ranks (one process per GPU, launched by torch.distributed.run) the 500 samples of every pixel
+are split 63/62 over the ranks and the fixed-point accumulation buffers are summed by one RCCL
+all-reduce per frame, so the N-GPU frame equals the 1-GPU frame bit for bit ("strong" scaling:
+total work is fixed).  Scene and accumulation buffer are resident in HBM before the timed
+region; tone mapping and PPM output are outside it.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+PUBLISHED_MSAMPLES_S = 480.0e6 / 36000.0 / 1e6  # "ran ten hours" for this exact frame (reference README.md:2510)
+
+
+def algorithmic_flop(n_objects, rays, samples):
+    """Flops of the REFERENCE algorithm for this scene: a flat list tested in full for every ray.
+    23 flop per sphere test up to the discriminant sign (3 sub, 5 + 5 for the two dot products,
+    7 for c and the discriminant, 3 for comparisons), 60 per ray for the accepted hit, the scatter
+    and the sky, 40 per sample for jitter and camera ray."""
+    return rays * (n_objects * 23.0 + 60.0) + samples * 40.0
+
+
+def cpu_baseline(scene_path):
+    """The reference renderer itself (oracle/_ref/ref_b1, compiled from the unmodified sources in the
+    development container), one thread, on a bounded sample of the same workload; falls back to the
+    oracle's rand()-faithful port when that binary is absent."""
+    W, H, spp = 240, 160, 32
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_b1")
+    sample = f"config-2 scene and camera, {W}x{H}, {spp} spp, depth 50 ({W * H * spp / 1e6:.2f} Msamples)"
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            subprocess.run([ref, "render", "c2", str(W), str(H), str(spp), "50", "-", os.path.join(tmp, "o.f64")],
+                           check=True, capture_output=True)
+            dt = time.perf_counter() - t0
+        return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                "sample": sample + "; unmodified reference sources, g++ -O2, 1 thread"}
+    from raytracing_amd import abi
+    from tests import oracle_binding as ob
+    from tests.conftest import CAM_C2
+    scene = abi.load_scene(scene_path)
+    cam = ob.camera(*CAM_C2)
+    t0 = time.perf_counter()
+    ob.render(scene, cam, abi.render_params(W, H, spp, 50), rng=ob.RNG_RAND, assoc=ob.ASSOC_REFERENCE,
+              want_fixed=False)
+    dt = time.perf_counter() - t0
+    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": sample + "; oracle/rt_oracle.c, gcc -O2, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import abi, frame, lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene_path = os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc")
+    scene = abi.load_scene(scene_path)
+    n_objects = int(scene.nodes[scene.root]["child1"])
+    cam = lib.camera((12, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 3.0 / 2.0, 0.1, 10.0)
+    W, H, spp = args.width, args.height, args.spp
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = lib.Context(local_rank, stream.cuda_stream)
+    ctx.upload(scene)
+    accum = torch.zeros((H, W, 3), dtype=torch.int64, device=dev)
+
+    def render_fn(begin, count, buf):
+        ctx.render_device(cam, abi.render_params(W, H, count, args.depth, seed=1, sample_begin=begin), buf.data_ptr())
+
+    reduce_fn = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if world > 1 else None
+
+    def step():
+        frame.render_frame(render_fn, accum, spp, rank, world, reduce_fn)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.take_stats()  # drop warm-up statistics
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = ctx.take_stats()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    counts = torch.tensor([st["samples"], st["rays"], st["nan_samples"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    samples, rays, bad = (int(x) for x in counts.tolist())
+
+    if rank == 0:
+        assert samples == W * H * spp * args.steps, (samples, W * H * spp * args.steps)
+        value = samples / dt / 1e6
+        # roofline of the dominant kernel (k_render_spheres) on THIS rank: algorithmic flops of its launches
+        # over their event-timed duration on the kernel's own stream
+        k_ms = st["kernel_ms"] / max(1, st["kernel_launches"])
+        flop_per_launch = algorithmic_flop(n_objects, st["rays"], st["samples"]) / max(1, st["kernel_launches"])
+        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/sec (paths x spp / s), One-Weekend final scene",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": value / PUBLISHED_MSAMPLES_S, "dtype": "f64 (f32 screening pass)",
+            "data": "synthetic: the reference's random_scene() as rolled under g++/glibc, dumped to tests/golden/scene_c2.rtsc",
+            "config": {"workload": "One Weekend final random-spheres scene (BASELINE configs[1])", "objects": n_objects,
+                       "width": W, "height": H, "spp": spp, "max_depth": args.depth,
+                       "parallelism": f"spp split over {world} rank(s), one int64 all-reduce per frame"},
+            "mrays_per_s": rays / dt / 1e6, "rays_per_sample": rays / max(1, samples), "nan_samples": bad,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "k_render_spheres", "kernel_ms": k_ms,
+                         "flop_per_launch": flop_per_launch,
+                         "note": "FP32 vector roofline; flop = reference algorithm (flat list, 23 flop per "
+                                 "sphere test); HBM traffic per launch is the 23 MB accumulation buffer only, "
+                                 "see profiles/"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_path)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

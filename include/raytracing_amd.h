@@ -185,7 +185,8 @@ typedef struct rt_stats {
     uint64_t rays;          /* world.hit() calls (ray segments), as the reference counts them */
     uint64_t nan_samples;   /* samples whose colour was NaN/Inf and was dropped      */
     uint64_t overflow_rays; /* rays that took the slow exact path (candidate list full) */
-    double kernel_ms;       /* device time of the render kernel(s), HIP events        */
+    uint64_t kernel_launches; /* render kernel launches timed into kernel_ms (at most 256 per take) */
+    double kernel_ms;       /* summed device time of those launches, HIP events on the kernel's stream */
 } rt_stats;
 
 typedef struct rt_context rt_context;

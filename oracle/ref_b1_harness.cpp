@@ -178,6 +178,11 @@ int main(int argc, char** argv) {
                     world.objects.size(), nl, nm, nd);
         std::printf(" \"obj1_center\": [%.17g, %.17g, %.17g],\n", s1->center[0], s1->center[1], s1->center[2]);
         std::printf(" \"obj2_center\": [%.17g, %.17g, %.17g],\n", s2->center[0], s2->center[1], s2->center[2]);
+        // how many rand() calls random_scene() made: replay the default-seeded stream
+        srand(1);
+        int calls = 0;
+        while (rand() != next) ++calls;
+        std::printf(" \"scene_build_rand_calls\": %d,\n", calls);
         std::printf(" \"next_rand\": %d}\n", next);
         return 0;
     }

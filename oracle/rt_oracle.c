@@ -674,6 +674,25 @@ int orc_render(const rt_scene_desc* s, const rt_camera_desc* cam, const rt_rende
     return RT_OK;
 }
 
+/* Philox / forward-association fixed-point sums of image rows [row_begin, row_end) of the frame
+ * described by prm; fixed has (row_end-row_begin)*width*3 entries.  Rows are independent because
+ * every sample's random block is keyed by its pixel index.                                  */
+int orc_render_rows(const rt_scene_desc* s, const rt_camera_desc* cam, const rt_render_params* prm, int row_begin,
+                    int row_end, int has_time, int64_t* fixed) {
+    if (!s || !cam || !prm || !fixed || row_begin < 0 || row_end > prm->height || row_begin > row_end)
+        return RT_ERR_INVALID_ARGUMENT;
+    render_job jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.s = s; jb.cam = cam; jb.prm = prm;
+    jb.rng_mode = ORC_RNG_PHILOX; jb.assoc = ORC_ASSOC_FORWARD; jb.has_time = has_time;
+    jb.row_begin = row_begin; jb.row_end = row_end;
+    jb.accum = NULL;
+    /* render_rows indexes the output by absolute row: bias the pointer */
+    jb.fixed = fixed - (size_t)3 * (size_t)row_begin * (size_t)prm->width;
+    render_rows(&jb);
+    return RT_OK;
+}
+
 /* Pixel-centre closest-hit ids (definition: rt_first_hit in raytracing_amd.h). */
 int orc_first_hit(const rt_scene_desc* s, const rt_camera_desc* c, int W, int H, int32_t* ids) {
     if (!s || !c || !ids || s->nodes[s->root].kind != RT_NODE_LIST) return RT_ERR_INVALID_ARGUMENT;

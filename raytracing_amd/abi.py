@@ -76,7 +76,7 @@ class rt_render_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nan_samples", C.c_uint64),
-                ("overflow_rays", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("overflow_rays", C.c_uint64), ("kernel_launches", C.c_uint64), ("kernel_ms", C.c_double)]
 
 
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("material", "<i4"), ("child0", "<i4"), ("child1", "<i4"),

@@ -39,9 +39,12 @@ struct rt_context {
     size_t accum_elems = 0;
     int32_t* d_ids = nullptr;
     size_t ids_elems = 0;
-    double kernel_ms = 0.0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP event pairs around the render kernels launched since the last rt_context_take_stats
+    std::vector<hipEvent_t> ev_pool;  // [2*i] = start, [2*i+1] = stop
+    size_t ev_used = 0;               // pairs in use
 };
+
+static constexpr size_t MAX_TIMED_LAUNCHES = 256;
 
 static thread_local std::string g_create_detail;
 
@@ -119,8 +122,6 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 256);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 256);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "rt_context_create");
         rt_context_destroy(ctx);
@@ -144,8 +145,7 @@ void rt_context_destroy(rt_context* ctx) {
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_ids);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -316,9 +316,26 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (blocks < 1) blocks = 1;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    // time the kernel with an event pair on its own stream (the first MAX_TIMED_LAUNCHES launches
+    // after each rt_context_take_stats)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->ev_used < MAX_TIMED_LAUNCHES) {
+        if (ctx->ev_pool.size() < 2 * (ctx->ev_used + 1)) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(ctx, hipEventCreate(&a));
+            ctx->ev_pool.push_back(a);
+            HIP_TRY(ctx, hipEventCreate(&b));
+            ctx->ev_pool.push_back(b);
+        }
+        e0 = ctx->ev_pool[2 * ctx->ev_used];
+        e1 = ctx->ev_pool[2 * ctx->ev_used + 1];
+    }
+    if (e0) HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     HIP_TRY(ctx, launch_render_spheres(A, blocks, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (e1) {
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        ++ctx->ev_used;
+    }
     return RT_OK;
 }
 
@@ -346,12 +363,18 @@ int rt_context_take_stats(rt_context* ctx, rt_stats* out) {
     out->rays = h[1];
     out->nan_samples = h[2];
     out->overflow_rays = h[3];
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) {
-        (void)hipGetLastError();
-        ms = 0.0f;
+    double total = 0.0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            ms = 0.0f;
+        }
+        total += ms;
     }
-    out->kernel_ms = ms;  // the most recent render kernel
+    out->kernel_ms = total;
+    out->kernel_launches = (uint64_t)ctx->ev_used;
+    ctx->ev_used = 0;
     return RT_OK;
 }
 

@@ -68,14 +68,15 @@ __device__ __forceinline__ ScreenRay screen_prepare(d3 o, d3 d, double a /* |d|^
 
 typedef __attribute__((address_space(4))) SphereScreen ConstSphereScreen;
 
-__device__ __forceinline__ uint32_t screen_one(const ScreenRay& r, const SphereScreen s, uint32_t mask) {
-    float hb = __builtin_fmaf(-s.cx, r.dx, r.od);
-    hb = __builtin_fmaf(-s.cy, r.dy, hb);
-    hb = __builtin_fmaf(-s.cz, r.dz, hb);
-    float acc = r.e - s.k;
-    acc = __builtin_fmaf(r.p2ox, s.cx, acc);
-    acc = __builtin_fmaf(r.p2oy, s.cy, acc);
-    acc = __builtin_fmaf(r.p2oz, s.cz, acc);
+__device__ __forceinline__ uint32_t screen_one(const ScreenRay& r, const ConstSphereScreen* s, uint32_t mask) {
+    const float cx = s->cx, cy = s->cy, cz = s->cz, k = s->k;
+    float hb = __builtin_fmaf(-cx, r.dx, r.od);
+    hb = __builtin_fmaf(-cy, r.dy, hb);
+    hb = __builtin_fmaf(-cz, r.dz, hb);
+    float acc = r.e - k;
+    acc = __builtin_fmaf(r.p2ox, cx, acc);
+    acc = __builtin_fmaf(r.p2oy, cy, acc);
+    acc = __builtin_fmaf(r.p2oz, cz, acc);
     const float q = __builtin_fmaf(hb, hb, acc);
     return __builtin_amdgcn_alignbit(mask, __float_as_uint(q), 31);
 }
@@ -130,7 +131,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
         const ConstSphereScreen* sp = (const ConstSphereScreen*)(S.screen + g * SCREEN_GROUP);
         uint32_t mask = 0;
 #pragma unroll
-        for (int jj = 0; jj < SCREEN_GROUP; ++jj) mask = screen_one(sr, sp[jj], mask);
+        for (int jj = 0; jj < SCREEN_GROUP; ++jj) mask = screen_one(sr, sp + jj, mask);
         uint32_t cand = on ? ~mask : 0u;
         while (ballot(cand != 0u) != 0ull) {
             if (cand != 0u) {

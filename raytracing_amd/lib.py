@@ -102,7 +102,8 @@ def write_ppm(path, rgb) -> None:
 
 def stats_dict(st: abi.rt_stats) -> dict:
     return {"samples": int(st.samples), "rays": int(st.rays), "nan_samples": int(st.nan_samples),
-            "overflow_rays": int(st.overflow_rays), "kernel_ms": float(st.kernel_ms)}
+            "overflow_rays": int(st.overflow_rays), "kernel_launches": int(st.kernel_launches),
+            "kernel_ms": float(st.kernel_ms)}
 
 
 class Context:

@@ -1,0 +1,80 @@
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from raytracing_amd import abi  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def gold(name):
+    return os.path.join(GOLD, name)
+
+
+@pytest.fixture(scope="session")
+def kat_b1():
+    with open(gold("kat_b1.json")) as fp:
+        return json.load(fp)
+
+
+@pytest.fixture(scope="session")
+def scene_c1():
+    return abi.load_scene(gold("scene_c1.rtsc"))
+
+
+@pytest.fixture(scope="session")
+def scene_c2():
+    return abi.load_scene(gold("scene_c2.rtsc"))
+
+
+# camera arguments of the two book-1 configurations: (lookfrom, lookat, vup, vfov, aspect, aperture, focus)
+C1_LOOKFROM, C1_LOOKAT = (3, 3, 2), (0, 0, -1)
+CAM_C1 = (C1_LOOKFROM, C1_LOOKAT, (0, 1, 0), 20.0, 16.0 / 9.0, 2.0,
+          math.sqrt(sum((a - b) ** 2 for a, b in zip(C1_LOOKFROM, C1_LOOKAT))))
+CAM_C2 = ((12, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 3.0 / 2.0, 0.1, 10.0)
+
+
+def make_sphere_scene(spheres, materials, sky_mode=abi.RT_SKY_GRADIENT, background=(0, 0, 0)):
+    """Build a flat-list scene.  spheres: [(cx, cy, cz, r, material_index)];
+    materials: [("lambertian", (r,g,b)) | ("metal", (r,g,b), fuzz) | ("dielectric", ir)]"""
+    n = len(spheres)
+    nodes = np.zeros(n + 1, dtype=abi.NODE_DTYPE)
+    nodes[0]["kind"], nodes[0]["material"], nodes[0]["child0"], nodes[0]["child1"] = abi.RT_NODE_LIST, -1, 0, n
+    for i, (cx, cy, cz, r, m) in enumerate(spheres):
+        nd = nodes[i + 1]
+        nd["kind"], nd["material"], nd["child0"], nd["child1"] = abi.RT_NODE_SPHERE, m, -1, -1
+        nd["p"][:4] = (cx, cy, cz, r)
+    children = np.arange(1, n + 1, dtype=np.int32)
+    mats = np.zeros(len(materials), dtype=abi.MATERIAL_DTYPE)
+    texs = []
+    for i, m in enumerate(materials):
+        if m[0] == "lambertian":
+            t = np.zeros((), dtype=abi.TEXTURE_DTYPE)
+            t["kind"], t["a"], t["b"] = abi.RT_TEX_SOLID, -1, -1
+            t["p"][:3] = m[1]
+            texs.append(t)
+            mats[i]["kind"], mats[i]["texture"] = abi.RT_MAT_LAMBERTIAN, len(texs) - 1
+            mats[i]["albedo"] = m[1]
+        elif m[0] == "metal":
+            mats[i]["kind"], mats[i]["texture"] = abi.RT_MAT_METAL, -1
+            mats[i]["albedo"] = m[1]
+            mats[i]["param"] = min(m[2], 1.0)
+        elif m[0] == "dielectric":
+            mats[i]["kind"], mats[i]["texture"], mats[i]["param"] = abi.RT_MAT_DIELECTRIC, -1, m[1]
+        else:
+            raise ValueError(m)
+    textures = np.array(texs, dtype=abi.TEXTURE_DTYPE) if texs else np.zeros(0, dtype=abi.TEXTURE_DTYPE)
+    return abi.Scene(0, nodes, children, mats, textures, np.zeros(0, dtype=abi.PERLIN_DTYPE), [], sky_mode,
+                     tuple(background))

@@ -37,6 +37,9 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(abi.rt_scene_desc), C.POINTER(abi.rt_camera_desc),
                                  C.POINTER(abi.rt_render_params), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render_rows.restype = C.c_int
+        L.orc_render_rows.argtypes = [C.POINTER(abi.rt_scene_desc), C.POINTER(abi.rt_camera_desc),
+                                      C.POINTER(abi.rt_render_params), C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_first_hit.restype = C.c_int
         L.orc_first_hit.argtypes = [C.POINTER(abi.rt_scene_desc), C.POINTER(abi.rt_camera_desc), C.c_int, C.c_int,
                                     C.c_void_p]
@@ -73,6 +76,18 @@ def render(scene: abi.Scene, cam, params, rng=RNG_PHILOX, assoc=ASSOC_FORWARD, h
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return accum, fixed, {"rays": int(stats[0]), "nan_samples": int(stats[1]), "draws": int(stats[2])}
+
+
+def render_rows(scene: abi.Scene, cam, params, row_begin, row_end, has_time=False):
+    """Fixed-point sums (Philox draws, forward association) of image rows [row_begin, row_end) of the
+    full frame described by `params`; rows of a frame are independent of each other."""
+    d = scene.desc()
+    fixed = np.zeros((row_end - row_begin, params.width, 3), dtype=np.int64)
+    rc = lib().orc_render_rows(C.byref(d), C.byref(cam), C.byref(params), row_begin, row_end, int(has_time),
+                               fixed.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"orc_render_rows failed: {rc}")
+    return fixed
 
 
 def first_hit(scene: abi.Scene, cam, W, H):

@@ -1,0 +1,255 @@
+"""Parity of the gfx950 kernels, called through the C ABI, against the oracle and the golden
+data of the reference.  Bars:
+  * first-hit ids: bit-exact against the reference's ids (sha256 / full arrays);
+  * rendered colour sums: bit-exact against the oracle run with the same Philox draws
+    (the kernels compute in double with the reference's operation order);
+  * against the reference's own rand()-driven images: statistical, with the tolerance derived
+    from the measured reference-vs-reference noise, written next to each assertion.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import oracle_binding as ob
+from tests.conftest import CAM_C1, CAM_C2, gold, make_sphere_scene
+
+pytestmark = pytest.mark.gpu
+
+FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_sums(scene, cam, p):
+    _, fixed, st = ob.render(scene, cam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=16)
+    return fixed.astype(np.float64) / FRAC, st
+
+
+# ------------------------------------------------------------------ first-hit ids (bit-exact gate)
+def test_first_hit_config2_full_size(ctx, scene_c2, kat_b1):
+    ctx.upload(scene_c2)
+    ids = ctx.first_hit(lib.camera(*CAM_C2), 1200, 800)
+    assert sha(ids) == kat_b1["c2_firsthit_1200x800"]["sha256"]
+    assert np.array_equal(ids, np.load(gold("c2_firsthit_1200x800.npz"))["ids"].astype(np.int32))
+
+
+def test_first_hit_config1(ctx, scene_c1, kat_b1):
+    ctx.upload(scene_c1)
+    ids = ctx.first_hit(lib.camera(*CAM_C1), 400, 225)
+    assert sha(ids) == kat_b1["c1_firsthit_400x225"]["sha256"]
+
+
+def test_first_hit_screen_never_drops_a_hit(ctx, scene_c2):
+    """Float screen on/off and the oracle agree from awkward viewpoints (grazing, inside glass, far away)."""
+    ctx.upload(scene_c2)
+    views = [((0.0, 1.0, 0.0), (4, 1, 0)),            # inside the big glass sphere
+             ((0, 0.2001, 30), (0, 0.2, 0)),           # skimming the ground
+             ((4000, 3000, 2500), (0, 0, 0)),          # far away: large |o|
+             ((-4, 1, 2.5), (4, 1, 0)),
+             ((0.3, 0.21, 0.3), (-11, 0.2, -11))]
+    for lf, la in views:
+        cam = lib.camera(lf, la, (0, 1, 0), 50.0, 1.5, 0.0, 10.0)
+        a = ctx.first_hit(cam, 300, 200)
+        ctx.set_exact_only(True)
+        b = ctx.first_hit(cam, 300, 200)
+        ctx.set_exact_only(False)
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, ob.first_hit(scene_c2, cam, 300, 200))
+
+
+# ------------------------------------------------------------------ rendered sums vs the oracle
+@pytest.mark.parametrize("which,W,H,spp,seed,begin", [
+    ("c1", 96, 54, 12, 1, 0),
+    ("c1", 37, 23, 5, 99, 17),       # ragged size, offset sample range
+    ("c2", 72, 48, 6, 1, 0),
+    ("c2", 64, 64, 3, 2 ** 40 + 5, 3),
+])
+def test_render_matches_oracle_bitwise(ctx, scene_c1, scene_c2, which, W, H, spp, seed, begin):
+    scene, camargs = (scene_c1, CAM_C1) if which == "c1" else (scene_c2, CAM_C2)
+    cam = lib.camera(*camargs)
+    p = abi.render_params(W, H, spp, 50, seed=seed, sample_begin=begin)
+    ctx.upload(scene)
+    got, st = ctx.render(cam, p)
+    want, ost = oracle_sums(scene, cam, p)
+    assert np.array_equal(got, want)
+    assert st["samples"] == W * H * spp and st["rays"] == ost["rays"] and st["nan_samples"] == 0
+
+
+def test_render_exact_only_is_identical(ctx, scene_c2):
+    cam = lib.camera(*CAM_C2)
+    p = abi.render_params(80, 50, 4, 50, seed=11)
+    ctx.upload(scene_c2)
+    a, _ = ctx.render(cam, p)
+    ctx.set_exact_only(True)
+    b, _ = ctx.render(cam, p)
+    ctx.set_exact_only(False)
+    assert np.array_equal(a, b)
+
+
+def test_sample_ranges_add_up_exactly(ctx, scene_c2):
+    """Splitting spp over calls (= over GPUs) gives the unsplit sums bit for bit."""
+    cam = lib.camera(*CAM_C2)
+    ctx.upload(scene_c2)
+    whole, _ = ctx.render(cam, abi.render_params(90, 60, 19, 50, seed=5))
+    parts = [ctx.render(cam, abi.render_params(90, 60, n, 50, seed=5, sample_begin=b))[0]
+             for b, n in ((0, 3), (3, 2), (5, 2), (7, 3), (10, 2), (12, 2), (14, 3), (17, 2))]
+    fixed_sum = sum((np.rint(x * FRAC).astype(np.int64) for x in parts))
+    assert np.array_equal(fixed_sum, np.rint(whole * FRAC).astype(np.int64))
+
+
+def test_depth_limits(ctx, scene_c1):
+    cam = lib.camera(*CAM_C1)
+    ctx.upload(scene_c1)
+    for depth in (1, 2, 5):
+        p = abi.render_params(48, 27, 6, depth, seed=4)
+        got, _ = ctx.render(cam, p)
+        want, _ = oracle_sums(scene_c1, cam, p)
+        assert np.array_equal(got, want)
+    black, st = ctx.render(cam, abi.render_params(48, 27, 6, 0, seed=4))
+    assert not black.any()
+
+
+def test_work_item_size_does_not_change_results(ctx, scene_c1, monkeypatch):
+    cam = lib.camera(*CAM_C1)
+    ctx.upload(scene_c1)
+    p = abi.render_params(50, 30, 21, 50, seed=8)
+    base, _ = ctx.render(cam, p)
+    for chunk in ("1", "5", "64"):
+        monkeypatch.setenv("RT_ITEM_SAMPLES", chunk)
+        again, _ = ctx.render(cam, p)
+        assert np.array_equal(base, again)
+
+
+# ------------------------------------------------------------------ synthetic edge cases
+def test_empty_world_is_pure_sky(ctx):
+    s = make_sphere_scene([], [("lambertian", (0.5, 0.5, 0.5))])
+    cam = lib.camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 2.0, 0.0, 1.0)
+    p = abi.render_params(32, 16, 3, 50)
+    ctx.upload(s)
+    got, st = ctx.render(cam, p)
+    want, _ = oracle_sums(s, cam, p)
+    assert np.array_equal(got, want) and st["rays"] == st["samples"]
+    assert (ctx.first_hit(cam, 32, 16) == -1).all()
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 64, 65, 200])
+def test_list_lengths_around_group_boundaries(ctx, n):
+    rng = np.random.default_rng(n)
+    sph = [(0, -1000, 0, 1000, 0)]
+    for _ in range(n - 1):
+        x, z = rng.uniform(-6, 6, 2)
+        sph.append((x, 0.3, z, 0.3, int(rng.integers(0, 4))))
+    mats = [("lambertian", (0.5, 0.6, 0.4)), ("metal", (0.8, 0.7, 0.6), 0.2), ("dielectric", 1.5),
+            ("lambertian", (0.9, 0.2, 0.2))]
+    s = make_sphere_scene(sph, mats)
+    cam = lib.camera((9, 2, 4), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.05, 9.0)
+    p = abi.render_params(45, 30, 4, 20, seed=n)
+    ctx.upload(s)
+    got, _ = ctx.render(cam, p)
+    want, _ = oracle_sums(s, cam, p)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.first_hit(cam, 45, 30), ob.first_hit(s, cam, 45, 30))
+
+
+def test_candidate_overflow_takes_the_exact_path(ctx):
+    """48 nested glass shells: every central ray has more candidates than LDS slots."""
+    sph = [(0, 0, 0, 1.0 + 0.05 * k, 0) for k in range(48)]
+    s = make_sphere_scene(sph, [("dielectric", 1.1)])
+    cam = lib.camera((0, 0, 8), (0, 0, 0), (0, 1, 0), 30.0, 1.0, 0.0, 8.0)
+    p = abi.render_params(24, 24, 2, 12, seed=6)
+    ctx.upload(s)
+    got, st = ctx.render(cam, p)
+    want, _ = oracle_sums(s, cam, p)
+    assert st["overflow_rays"] > 0
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.first_hit(cam, 24, 24), ob.first_hit(s, cam, 24, 24))
+
+
+def test_extreme_geometry_screen_is_conservative(ctx):
+    """Huge, tiny, distant and negative-radius spheres; origin far from the world origin."""
+    rng = np.random.default_rng(5)
+    sph = [(0, -1e5, 0, 1e5, 0), (3000, 5, 3000, 4, 1), (3000.5, 5, 3006, -1.5, 2), (2990, 2, 3003, 1e-3, 1)]
+    for _ in range(60):
+        c = rng.uniform(-40, 40, 3) + np.array([3000, 10, 3000])
+        sph.append((c[0], abs(c[1]) + 0.5, c[2], float(rng.choice([0.01, 0.5, 3.0, 25.0])), int(rng.integers(0, 3))))
+    s = make_sphere_scene(sph, [("lambertian", (0.5, 0.5, 0.5)), ("metal", (0.9, 0.9, 0.9), 0.0), ("dielectric", 1.5)])
+    cam = lib.camera((3030, 12, 3040), (3000, 5, 3000), (0, 1, 0), 60.0, 1.0, 0.0, 10.0)
+    ctx.upload(s)
+    a = ctx.first_hit(cam, 200, 200)
+    assert np.array_equal(a, ob.first_hit(s, cam, 200, 200))
+    p = abi.render_params(40, 40, 3, 30, seed=2)
+    got, _ = ctx.render(cam, p)
+    want, _ = oracle_sums(s, cam, p)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ against the reference's own images
+def test_config1_image_vs_reference(ctx, scene_c1):
+    """Full config 1 (400x225, 100 spp, depth 50) against the reference's image.
+    Two independent 100-spp renders differ by Monte-Carlo noise only; the tolerance is 1.15 x the
+    difference between two GPU renders with different seeds, plus an image-mean bias bound of 1e-3."""
+    cam = lib.camera(*CAM_C1)
+    ctx.upload(scene_c1)
+    ref = np.load(gold("c1_400x225x100_ref.npz"))["radiance"].astype(np.float64)
+    a = ctx.render(cam, abi.render_params(400, 225, 100, 50, seed=1))[0] / 100.0
+    b = ctx.render(cam, abi.render_params(400, 225, 100, 50, seed=2))[0] / 100.0
+    rmse = lambda x, y: float(np.sqrt(np.mean((x - y) ** 2)))
+    assert rmse(a, ref) <= 1.15 * rmse(a, b)
+    assert np.abs(a.reshape(-1, 3).mean(0) - ref.reshape(-1, 3).mean(0)).max() < 1e-3
+    big = ctx.render(cam, abi.render_params(400, 225, 1600, 50, seed=3))[0] / 1600.0
+    # a 1600-spp GPU image must be CLOSER to the reference than any 100-spp image is
+    assert rmse(big, ref) < 0.8 * rmse(a, ref)
+
+
+def test_config2_image_vs_reference(ctx, scene_c2, kat_b1):
+    """Config-2 scene at 300x200 against the mean of four 500-spp reference renders (2000 spp).
+    Measured reference-vs-reference RMSE at 500 spp is r (about 0.0071); a correct 500-spp image lies
+    at r*sqrt(5/8) of the 2000-spp mean.  Gates: RMSE <= 1.1 * r * sqrt(5/8), PSNR of the 8-bit images
+    >= 41.5 dB, image-mean radiance within 3e-4 per channel."""
+    k = kat_b1["c2_300x200"]
+    r = float(np.mean(k["pair_rmse_500spp"]))
+    ref = np.load(gold("c2_300x200_ref.npz"))
+    mean2000 = ref["radiance"].astype(np.float64)
+    cam = lib.camera(*CAM_C2)
+    ctx.upload(scene_c2)
+    img = ctx.render(cam, abi.render_params(300, 200, 500, 50, seed=1))[0] / 500.0
+    rmse = float(np.sqrt(np.mean((img - mean2000) ** 2)))
+    assert rmse <= 1.1 * r * np.sqrt(5.0 / 8.0), (rmse, r)
+    assert np.abs(img.reshape(-1, 3).mean(0) - np.array(k["image_mean_rgb"])).max() < 3e-4
+    g8 = lib.write_color(img, 1).astype(np.float64)
+    r8 = lib.write_color(ref["one_seed"].astype(np.float64), 1).astype(np.float64)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((g8 - r8) ** 2))
+    assert psnr >= 41.5, psnr
+
+
+# ------------------------------------------------------------------ full size: size-independent properties
+def test_config2_full_size_properties(ctx, scene_c2):
+    cam = lib.camera(*CAM_C2)
+    ctx.upload(scene_c2)
+    W, H = 1200, 800
+    a, st = ctx.render(cam, abi.render_params(W, H, 8, 50, seed=1))
+    assert st["samples"] == W * H * 8 and st["nan_samples"] == 0 and st["overflow_rays"] == 0
+    assert 2.80 < st["rays"] / st["samples"] < 2.89   # the reference measures 2.84 rays per sample
+    b, _ = ctx.render(cam, abi.render_params(W, H, 8, 50, seed=1))
+    assert np.array_equal(a, b)                        # order-independent accumulation
+    lo, _ = ctx.render(cam, abi.render_params(W, H, 3, 50, seed=1))
+    hi, _ = ctx.render(cam, abi.render_params(W, H, 5, 50, seed=1, sample_begin=3))
+    assert np.array_equal(np.rint(lo * FRAC).astype(np.int64) + np.rint(hi * FRAC).astype(np.int64),
+                          np.rint(a * FRAC).astype(np.int64))
+    # every value is a sum of 8 colours in [0,1]
+    assert a.min() >= 0.0 and a.max() <= 8.0
+    # oracle spot check of three full-resolution rows
+    p = abi.render_params(W, H, 8, 50, seed=1)
+    for row in (0, 399, 799):
+        assert np.array_equal(a[row], ob.render_rows(scene_c2, cam, p, row, row + 1)[0] / FRAC)
