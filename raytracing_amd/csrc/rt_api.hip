@@ -167,13 +167,15 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     if (sc->sky_mode != RT_SKY_GRADIENT && sc->sky_mode != RT_SKY_BACKGROUND)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad sky_mode");
 
-    const int n_groups = (n + SCREEN_GROUP - 1) / SCREEN_GROUP;
-    std::vector<SphereScreen> screen((size_t)std::max(1, n_groups) * SCREEN_GROUP);
+    const int n_pairs = (n + 1) / 2;
+    std::vector<SpherePair> screen((size_t)std::max(1, n_pairs));
     std::vector<SphereExact> exact((size_t)std::max(1, n));
     std::vector<int32_t> material_of((size_t)std::max(1, n));
-    for (auto& s : screen) {  // padding never yields a candidate: q = -huge
-        s.cx = s.cy = s.cz = 0.0f;
-        s.k = 3.0e38f;
+    for (auto& s : screen) {  // the pad of an odd list never yields a candidate: q = -huge
+        for (int h = 0; h < 2; ++h) {
+            s.cx[h] = s.cy[h] = s.cz[h] = 0.0f;
+            s.k[h] = 3.0e38f;
+        }
     }
     for (int i = 0; i < n; ++i) {
         const int ni = sc->children[root.child0 + i];
@@ -191,7 +193,11 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
         // round k toward -inf so the float image never shrinks the margin
         float kf = (float)k;
         if ((double)kf > k) kf = std::nextafterf(kf, -INFINITY);
-        screen[i] = SphereScreen{(float)cx, (float)cy, (float)cz, kf};
+        SpherePair& sp = screen[i / 2];
+        sp.cx[i & 1] = (float)cx;
+        sp.cy[i & 1] = (float)cy;
+        sp.cz[i & 1] = (float)cz;
+        sp.k[i & 1] = kf;
     }
     std::vector<MaterialDev> mats((size_t)std::max(1, sc->n_materials));
     for (int i = 0; i < sc->n_materials; ++i) {
@@ -226,19 +232,20 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    HIP_TRY(ctx, hipMalloc(&ctx->d_screen, screen.size() * sizeof(SphereScreen)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_screen, screen.size() * sizeof(SpherePair)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_exact, exact.size() * sizeof(SphereExact)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_material_of, material_of.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_materials, mats.size() * sizeof(MaterialDev)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_screen, screen.data(), screen.size() * sizeof(SphereScreen), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_screen, screen.data(), screen.size() * sizeof(SpherePair), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_exact, exact.data(), exact.size() * sizeof(SphereExact), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_material_of, material_of.data(), material_of.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
 
     SphereListDev& S = ctx->scene;
     S.n = n;
-    S.n_groups = n_groups;
-    S.screen = (const SphereScreen*)ctx->d_screen;
+    S.n_full_groups = n / SCREEN_GROUP;
+    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
+    S.screen = (const SpherePair*)ctx->d_screen;
     S.exact = (const SphereExact*)ctx->d_exact;
     S.material_of = (const int32_t*)ctx->d_material_of;
     S.materials = (const MaterialDev*)ctx->d_materials;
@@ -274,7 +281,7 @@ static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const r
 }
 
 static int chunk_for(const rt_render_params* p) {
-    int chunk = 16;
+    int chunk = 8;
     if (const char* s = std::getenv("RT_ITEM_SAMPLES")) {
         int v = std::atoi(s);
         if (v >= 1) chunk = v;

@@ -12,11 +12,13 @@ namespace rtd {
 //
 // Two images of every sphere live in HBM (a 487-sphere world is 7.8 KB + 15.6 KB, so both
 // stay in the scalar / vector caches for the whole render):
-//  - SphereScreen, 16 B, float: read with wave-uniform scalar loads by the screening pass;
+//  - SpherePair, 32 B, float: two consecutive spheres interleaved component by component, read
+//    with wave-uniform scalar loads by the screening pass.  Each member is one 64-bit SGPR pair,
+//    i.e. one operand of a packed FP32 instruction that works on both spheres at once;
 //  - SphereExact, 32 B, double: gathered per lane by the exact pass for the few candidates.
-struct SphereScreen {
-    float cx, cy, cz;
-    float k;  // |c|^2 - r^2 - margin(c, r), rounded from double; see screen pass
+struct SpherePair {
+    float cx[2], cy[2], cz[2];
+    float k[2];  // |c|^2 - r^2 - margin(c, r), rounded down from double; see screen pass
 };
 struct SphereExact {
     double cx, cy, cz, radius;
@@ -28,13 +30,14 @@ struct MaterialDev {
     double param;       // fuzz / ir
 };
 
-constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word
+constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
 
 struct SphereListDev {
     int32_t n;         // spheres in list order (= object ids)
-    int32_t n_groups;  // ceil(n / SCREEN_GROUP); the screen image is padded to a full group
-    const SphereScreen* screen;
+    int32_t n_full_groups;  // n / SCREEN_GROUP: groups screened by the unrolled loop
+    int32_t n_tail_pairs;   // pairs of the last, partial group (0..15); an odd sphere is padded
+    const SpherePair* screen;
     const SphereExact* exact;
     const int32_t* material_of;
     const MaterialDev* materials;

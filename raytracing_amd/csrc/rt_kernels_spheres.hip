@@ -43,42 +43,59 @@ namespace rtd {
 //     m_o = 2^-18 |o|^2,   m_c = 2^-18 (|c|^2 + r^2)        (2^-18 = 64 eps)
 // exceed that, so a sphere whose reference discriminant (a double, relative error 1e-15)
 // is >= 0 always yields q > 0.  The sign bit of q is shifted into the mask: 0 = candidate.
+//
+// Issue rates measured on gfx950 (tools/ubench): a wave64 v_fma_f32 whose operands are all
+// VGPRs issues every ~2.2 cycles, but with an SGPR operand every ~4.2 cycles; v_pk_fma_f32
+// (two FMAs per lane) also issues every ~4.1 cycles and accepts an SGPR pair.  The 8 ops are
+// therefore done on PAIRS of spheres with packed math: 8 packed ops + 2 v_alignbit per pair,
+// 23 cycles per sphere per SIMD at 4 waves/SIMD against 31 for the unpacked form.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct ScreenRay {
-    float dx, dy, dz;     // d^
-    float p2ox, p2oy, p2oz;  // 2 o
-    float od;             // o . d^
-    float e;              // m_o - |o|^2
+    f2 ndx, ndy, ndz;     // -d^, both halves equal
+    f2 p2ox, p2oy, p2oz;  // 2 o
+    f2 od;                // o . d^
+    f2 e;                 // m_o - |o|^2
 };
+
+__device__ __forceinline__ f2 splat(double x) {
+    const float f = (float)x;
+    return f2{f, f};
+}
 
 __device__ __forceinline__ ScreenRay screen_prepare(d3 o, d3 d, double a /* |d|^2 */) {
     const double inv_len = 1.0 / sqrt(a);
     const d3 dh = inv_len * d;
     const double oo = len2(o);
     ScreenRay s;
-    s.dx = (float)dh.x;
-    s.dy = (float)dh.y;
-    s.dz = (float)dh.z;
-    s.p2ox = (float)(2.0 * o.x);
-    s.p2oy = (float)(2.0 * o.y);
-    s.p2oz = (float)(2.0 * o.z);
-    s.od = (float)dot(o, dh);
-    s.e = (float)(oo * (0x1p-18 - 1.0));
+    s.ndx = splat(-dh.x);
+    s.ndy = splat(-dh.y);
+    s.ndz = splat(-dh.z);
+    s.p2ox = splat(2.0 * o.x);
+    s.p2oy = splat(2.0 * o.y);
+    s.p2oz = splat(2.0 * o.z);
+    s.od = splat(dot(o, dh));
+    s.e = splat(oo * (0x1p-18 - 1.0));
     return s;
 }
 
-typedef __attribute__((address_space(4))) SphereScreen ConstSphereScreen;
+typedef __attribute__((address_space(4))) SpherePair ConstSpherePair;
 
-__device__ __forceinline__ uint32_t screen_one(const ScreenRay& r, const ConstSphereScreen* s, uint32_t mask) {
-    const float cx = s->cx, cy = s->cy, cz = s->cz, k = s->k;
-    float hb = __builtin_fmaf(-cx, r.dx, r.od);
-    hb = __builtin_fmaf(-cy, r.dy, hb);
-    hb = __builtin_fmaf(-cz, r.dz, hb);
-    float acc = r.e - k;
-    acc = __builtin_fmaf(r.p2ox, cx, acc);
-    acc = __builtin_fmaf(r.p2oy, cy, acc);
-    acc = __builtin_fmaf(r.p2oz, cz, acc);
-    const float q = __builtin_fmaf(hb, hb, acc);
-    return __builtin_amdgcn_alignbit(mask, __float_as_uint(q), 31);
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Screens the two spheres of *s; appends their sign bits (first sphere first) to mask.
+__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const ConstSpherePair* s, uint32_t mask) {
+    const f2 cx{s->cx[0], s->cx[1]}, cy{s->cy[0], s->cy[1]}, cz{s->cz[0], s->cz[1]}, k{s->k[0], s->k[1]};
+    f2 hb = pk_fma(cx, r.ndx, r.od);
+    hb = pk_fma(cy, r.ndy, hb);
+    hb = pk_fma(cz, r.ndz, hb);
+    f2 acc = r.e - k;
+    acc = pk_fma(r.p2ox, cx, acc);
+    acc = pk_fma(r.p2oy, cy, acc);
+    acc = pk_fma(r.p2oz, cz, acc);
+    const f2 q = pk_fma(hb, hb, acc);
+    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
+    return __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
 }
 
 // ---------------------------------------------------------------- exact pass
@@ -125,13 +142,22 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
 
     const ScreenRay sr = screen_prepare(o, d, a);
     uint32_t cnt = 0;
-    for (int g = 0; g < S.n_groups; ++g) {
-        // The screen image is immutable for the whole launch: address it through the constant
-        // address space so that the wave-uniform reads become scalar loads (SGPR operands).
-        const ConstSphereScreen* sp = (const ConstSphereScreen*)(S.screen + g * SCREEN_GROUP);
+    // The screen image is immutable for the whole launch: address it through the constant
+    // address space so that the wave-uniform reads become scalar loads (SGPR operands).
+    const ConstSpherePair* sp = (const ConstSpherePair*)S.screen;
+    const int n_groups = S.n_full_groups + (S.n_tail_pairs > 0 ? 1 : 0);
+    for (int g = 0; g < n_groups; ++g) {
         uint32_t mask = 0;
+        if (g < S.n_full_groups) {
 #pragma unroll
-        for (int jj = 0; jj < SCREEN_GROUP; ++jj) mask = screen_one(sr, sp + jj, mask);
+            for (int jj = 0; jj < SCREEN_GROUP / 2; ++jj) mask = screen_pair(sr, sp + jj, mask);
+            sp += SCREEN_GROUP / 2;
+        } else {  // last, partial group: bits of absent spheres read "no candidate"
+            mask = ~0u;
+#pragma unroll 1
+            for (int jj = 0; jj < S.n_tail_pairs; ++jj) mask = screen_pair(sr, sp + jj, mask);
+            mask = ~(~mask << (SCREEN_GROUP - 2 * S.n_tail_pairs));
+        }
         uint32_t cand = on ? ~mask : 0u;
         while (ballot(cand != 0u) != 0ull) {
             if (cand != 0u) {
@@ -206,7 +232,10 @@ __device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
 }
 
 // ---------------------------------------------------------------- render kernel
-__global__ void __launch_bounds__(256) k_render_spheres(const RenderArgs A) {
+#ifndef RT_MIN_WAVES_PER_SIMD
+#define RT_MIN_WAVES_PER_SIMD 4
+#endif
+__global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A) {
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];

@@ -13,7 +13,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+# RT_LIB_PATH selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "libraytracing_amd.so")
 
 _lib = None
 
