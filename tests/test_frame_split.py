@@ -1,0 +1,78 @@
+"""The N>1 path on CPU: sample partition, one all-reduce of fixed-point buffers, tone map.
+
+The GPU renderer is replaced by the oracle (same Philox draws, same fixed-point sums), and
+torch.distributed runs over gloo with world_size 2 and 3, so the logic that bench.py and a
+multi-GPU caller use -- raytracing_amd.frame -- is exercised end to end without a GPU.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracing_amd import abi, frame
+from tests import oracle_binding as ob
+from tests.conftest import CAM_C2, gold
+
+W, H, SPP, SEED = 40, 28, 11, 9
+
+
+def test_sample_ranges_partition_exactly():
+    for spp in (0, 1, 7, 62, 500, 10000):
+        for world in (1, 2, 3, 8, 16):
+            got = [frame.sample_range(spp, r, world) for r in range(world)]
+            covered = [s for b, n in got for s in range(b, b + n)]
+            assert covered == list(range(spp))
+            counts = [n for _, n in got]
+            assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
+    assert [frame.sample_range(500, r, 8)[1] for r in range(8)] == [63, 63, 63, 63, 62, 62, 62, 62]
+    with pytest.raises(ValueError):
+        frame.sample_range(10, 2, 2)
+
+
+def _oracle_render_fn(scene, cam):
+    def fn(begin, count, accum):
+        p = abi.render_params(W, H, count, 50, seed=SEED, sample_begin=begin)
+        _, fixed, _ = ob.render(scene, cam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=2)
+        accum += torch.from_numpy(fixed)
+    return fn
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = abi.load_scene(gold("scene_c2.rtsc"))
+        cam = ob.camera(*CAM_C2)
+        accum = torch.zeros((H, W, 3), dtype=torch.int64)
+        frame.render_frame(_oracle_render_fn(scene, cam), accum, SPP, rank, world,
+                           lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), accum.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_frame_equals_unsplit_frame(world, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    scene = abi.load_scene(gold("scene_c2.rtsc"))
+    cam = ob.camera(*CAM_C2)
+    whole = torch.zeros((H, W, 3), dtype=torch.int64)
+    frame.render_frame(_oracle_render_fn(scene, cam), whole, SPP)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert np.array_equal(got, whole.numpy()), f"rank {r} differs from the single-process frame"
+    # every rank can tone-map on its own: identical 8-bit images
+    sums = whole.numpy().astype(np.float64) / 2.0 ** abi.RT_ACCUM_FRAC_BITS
+    assert ob.write_color(sums, SPP).shape == (H, W, 3)
