@@ -33,7 +33,7 @@ extern "C" {
 enum {
     RT_OK = 0,
     RT_ERR_INVALID_ARGUMENT = 1,   /* null pointer, bad size, bad index in a scene array   */
-    RT_ERR_UNSUPPORTED_SCENE = 2,  /* scene graph uses a construct no kernel covers (yet)  */
+    RT_ERR_UNSUPPORTED_SCENE = 2,  /* scene graph uses a construct no kernel covers         */
     RT_ERR_NO_DEVICE = 3,          /* no gfx950 device visible / bad device ordinal        */
     RT_ERR_HIP = 4,                /* a HIP runtime call failed (see rt_last_error_detail) */
     RT_ERR_NO_SCENE = 5,           /* render / first-hit called before rt_scene_upload     */
@@ -227,6 +227,10 @@ int rt_context_synchronize(rt_context* ctx);
 /* Validation switch: when on, kernels skip their float screening pass and test every object
  * in double.  Results must be identical either way; only the speed differs. */
 int rt_context_set_exact_only(rt_context* ctx, int on);
+/* Validation switch, read by the next rt_scene_upload: when on, a flat list of spheres is laid out and
+ * rendered as a general scene graph instead of by the dedicated sphere-list kernels.  Results must be
+ * identical either way. */
+int rt_context_set_force_graph(rt_context* ctx, int on);
 /* Statistics of everything rendered since the last call of this function (synchronises). */
 int rt_context_take_stats(rt_context* ctx, rt_stats* out);
 

@@ -64,7 +64,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  *              word `slot` of that block: (word >> 1) / 2^31, the same 31-bit grid.
  * Sites: 0 = camera ray; 1+b = ray segment b (its medium draws and the scatter after it).
  * Tries: 0,1,2,.. = successive rejection-sampling attempts; ORC_TRY_TIME = shutter time;
- *        ORC_TRY_MEDIUM + m = the m-th constant_medium draw of the segment.               */
+ *        ORC_TRY_MEDIUM + i = the draw of the constant_medium whose node index is i.      */
 #define ORC_TRY_TIME 0x80000000u
 #define ORC_TRY_MEDIUM 0x40000000u
 
@@ -305,7 +305,9 @@ static int hit_node(hit_ctx* cx, int idx, const ray_t* r, double t_min, double t
         if (rec1.t < 0) rec1.t = 0;
         const double ray_length = vlen(r->dir);
         const double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
-        rng_call(cx->rng, cx->site, ORC_TRY_MEDIUM + cx->rng->medium_draws);
+        /* Philox: keyed by the medium's node index, so that the draw does not depend on the order in
+         * which a traversal meets the media of a segment */
+        rng_call(cx->rng, cx->site, ORC_TRY_MEDIUM + (uint32_t)idx);
         cx->rng->medium_draws++;
         const double hit_distance = n->p[0] * log(rng_draw(cx->rng, 0));
         if (hit_distance > distance_inside_boundary) return 0;

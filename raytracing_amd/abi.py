@@ -135,8 +135,13 @@ class Scene:
 
 def load_scene(path) -> Scene:
     """Read an RTSCENE1 file (layout: include/rt_scene_io.h)."""
-    with open(path, "rb") as fp:
-        blob = fp.read()
+    if str(path).endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rb") as fp:
+            blob = fp.read()
+    else:
+        with open(path, "rb") as fp:
+            blob = fp.read()
     if blob[:8] != b"RTSCENE1":
         raise ValueError(f"{path}: not an RTSCENE1 file")
     root, n_nodes, n_children, n_mat, n_tex, n_perlin, n_img, sky = struct.unpack_from("<8i", blob, 8)

@@ -1,7 +1,12 @@
 // C ABI of the library (include/raytracing_amd.h): context, scene upload, render, first hit.
 // Host code only; the kernels live in rt_kernels_*.hip.
+//
+// A scene is laid out for one of two kernel families at upload:
+//   sphere list   root list of spheres with book-1 materials  -> rt_kernels_spheres.hip
+//   scene graph   everything else the reference can build      -> rt_kernels_scene.hip
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,22 +20,24 @@
 
 using namespace rtd;
 
+enum ScenePath { PATH_NONE = 0, PATH_SPHERE_LIST = 1, PATH_GRAPH = 2 };
+
 struct rt_context {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 0;
-    int blocks_per_cu = 0;
+    int blocks_per_cu_spheres = 0;
+    int blocks_per_cu_scene = 0;
+    int blocks_override = 0;
     std::string detail;
-    bool exact_only = false;  // validation: bypass the float screen
+    bool exact_only = false;     // validation: bypass the float screen
+    bool force_graph = false;    // validation: lay every scene out as a scene graph
 
-    // scene (sphere list)
-    bool have_scene = false;
-    SphereListDev scene{};
-    void* d_screen = nullptr;
-    void* d_exact = nullptr;
-    void* d_material_of = nullptr;
-    void* d_materials = nullptr;
+    ScenePath path = PATH_NONE;
+    SphereListDev spheres{};
+    SceneDev graph{};
+    std::vector<void*> scene_allocs;  // device memory owned by the current scene
 
     // per-context device scratch, allocated once
     uint32_t* d_counter = nullptr;  // work-queue head
@@ -62,6 +69,346 @@ static int hip_fail(rt_context* ctx, hipError_t e, const char* where) {
         if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr);  \
     } while (0)
 
+static void free_scene(rt_context* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->path = PATH_NONE;
+}
+
+// hipMalloc + hipMemcpy of a host vector; the allocation is owned by the scene.
+template <class T>
+static int to_device(rt_context* ctx, const std::vector<T>& host, const T** out) {
+    void* d = nullptr;
+    const size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&d, bytes));
+    ctx->scene_allocs.push_back(d);
+    if (!host.empty()) HIP_TRY(ctx, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ scene validation
+struct GraphCheck {
+    const rt_scene_desc* sc;
+    std::string error;
+    int code = RT_OK;
+    std::vector<int32_t> parent_xf, top_of;
+    std::vector<uint8_t> visited;
+
+    bool bad(int code_, const std::string& what) {
+        if (code == RT_OK) {
+            code = code_;
+            error = what;
+        }
+        return false;
+    }
+    bool material_ok(int m) {
+        if (m < 0 || m >= sc->n_materials || !sc->materials) return bad(RT_ERR_INVALID_ARGUMENT, "material index out of range");
+        const rt_material& mt = sc->materials[m];
+        switch (mt.kind) {
+        case RT_MAT_LAMBERTIAN:
+        case RT_MAT_DIFFUSE_LIGHT:
+        case RT_MAT_ISOTROPIC: return texture_ok(mt.texture, 0);
+        case RT_MAT_METAL:
+        case RT_MAT_DIELECTRIC: return true;
+        default: return bad(RT_ERR_INVALID_ARGUMENT, "unknown material kind " + std::to_string(mt.kind));
+        }
+    }
+    bool texture_ok(int t, int depth) {
+        if (t < 0 || t >= sc->n_textures || !sc->textures) return bad(RT_ERR_INVALID_ARGUMENT, "texture index out of range");
+        const rt_texture& tx = sc->textures[t];
+        switch (tx.kind) {
+        case RT_TEX_SOLID: return true;
+        case RT_TEX_CHECKER:
+            if (depth >= 3) return bad(RT_ERR_LIMIT, "checker textures nested more than 3 deep");
+            return texture_ok(tx.a, depth + 1) && texture_ok(tx.b, depth + 1);
+        case RT_TEX_NOISE:
+            if (tx.a < 0 || tx.a >= sc->n_perlins || !sc->perlins) return bad(RT_ERR_INVALID_ARGUMENT, "perlin index out of range");
+            return true;
+        case RT_TEX_IMAGE:
+            if (tx.a >= sc->n_images || (tx.a >= 0 && !sc->images)) return bad(RT_ERR_INVALID_ARGUMENT, "image index out of range");
+            return true;
+        default: return bad(RT_ERR_INVALID_ARGUMENT, "unknown texture kind " + std::to_string(tx.kind));
+        }
+    }
+    static bool is_prim(int kind) {
+        return kind == RT_NODE_SPHERE || kind == RT_NODE_MOVING_SPHERE || kind == RT_NODE_XY_RECT ||
+               kind == RT_NODE_XZ_RECT || kind == RT_NODE_YZ_RECT;
+    }
+    bool child_range_ok(const rt_node& n) {
+        if (n.child0 < 0 || n.child1 < 0 || (int64_t)n.child0 + n.child1 > sc->n_children || (n.child1 > 0 && !sc->children))
+            return bad(RT_ERR_INVALID_ARGUMENT, "child range outside children[]");
+        return true;
+    }
+    // A constant_medium boundary: primitives, or a list/box of primitives, under translate / rotate_y levels.
+    bool boundary_ok(int idx) {
+        int depth = 0;
+        while (true) {
+            if (idx < 0 || idx >= sc->n_nodes) return bad(RT_ERR_INVALID_ARGUMENT, "node index out of range");
+            const rt_node& n = sc->nodes[idx];
+            if (n.kind == RT_NODE_TRANSLATE || n.kind == RT_NODE_ROTATE_Y) {
+                if (++depth > XF_DEPTH_CAP) return bad(RT_ERR_LIMIT, "medium boundary under too many instance levels");
+                idx = n.child0;
+                continue;
+            }
+            if (is_prim(n.kind)) return true;
+            if (n.kind == RT_NODE_LIST || n.kind == RT_NODE_BOX) {
+                if (!child_range_ok(n)) return false;
+                for (int i = 0; i < n.child1; ++i) {
+                    const int c = sc->children[n.child0 + i];
+                    if (c < 0 || c >= sc->n_nodes) return bad(RT_ERR_INVALID_ARGUMENT, "node index out of range");
+                    if (!is_prim(sc->nodes[c].kind))
+                        return bad(RT_ERR_UNSUPPORTED_SCENE, "constant_medium boundary: lists may only hold primitives");
+                }
+                return true;
+            }
+            return bad(RT_ERR_UNSUPPORTED_SCENE, "constant_medium boundary of node kind " + std::to_string(n.kind));
+        }
+    }
+    // Returns the traversal stack occupancy needed while `idx` (already popped) is processed.
+    int walk(int idx, int xf, int xf_depth, int top) {
+        if (code != RT_OK) return 0;
+        if (idx < 0 || idx >= sc->n_nodes) { bad(RT_ERR_INVALID_ARGUMENT, "node index out of range"); return 0; }
+        if (visited[idx]) { bad(RT_ERR_UNSUPPORTED_SCENE, "a node is referenced twice: the graph must be a tree"); return 0; }
+        visited[idx] = 1;
+        parent_xf[idx] = xf;
+        top_of[idx] = top;
+        const rt_node& n = sc->nodes[idx];
+        switch (n.kind) {
+        case RT_NODE_SPHERE:
+        case RT_NODE_MOVING_SPHERE:
+        case RT_NODE_XY_RECT:
+        case RT_NODE_XZ_RECT:
+        case RT_NODE_YZ_RECT: material_ok(n.material); return 0;
+        case RT_NODE_LIST:
+        case RT_NODE_BOX: {
+            if (!child_range_ok(n)) return 0;
+            if (n.child1 > 65534) { bad(RT_ERR_LIMIT, "more than 65534 objects in one list"); return 0; }
+            int need = 0;  // the list keeps one slot (its iterator) while a child is processed
+            for (int i = 0; i < n.child1; ++i) {
+                const int t = idx == sc->root ? i : top;
+                need = std::max(need, 2 + walk(sc->children[n.child0 + i], xf, xf_depth, t));
+            }
+            return need;
+        }
+        case RT_NODE_BVH: {
+            const int l = walk(n.child0, xf, xf_depth, top);
+            const int r = walk(n.child1, xf, xf_depth, top);
+            return std::max(2, std::max(1 + l, r));
+        }
+        case RT_NODE_TRANSLATE:
+        case RT_NODE_ROTATE_Y:
+            if (xf_depth + 1 > XF_DEPTH_CAP) { bad(RT_ERR_LIMIT, "more than 4 nested translate / rotate_y levels"); return 0; }
+            return std::max(2, 1 + walk(n.child0, idx, xf_depth + 1, top));
+        case RT_NODE_MEDIUM: {
+            material_ok(n.material);
+            boundary_ok(n.child0);
+            // the boundary subtree is evaluated in place, never pushed; mark it as used
+            std::vector<int> todo{n.child0};
+            while (!todo.empty() && code == RT_OK) {
+                const int b = todo.back();
+                todo.pop_back();
+                if (visited[b]) { bad(RT_ERR_UNSUPPORTED_SCENE, "a node is referenced twice: the graph must be a tree"); break; }
+                visited[b] = 1;
+                parent_xf[b] = xf;
+                top_of[b] = top;
+                const rt_node& bn = sc->nodes[b];
+                if (bn.kind == RT_NODE_TRANSLATE || bn.kind == RT_NODE_ROTATE_Y) todo.push_back(bn.child0);
+                if (bn.kind == RT_NODE_LIST || bn.kind == RT_NODE_BOX)
+                    for (int i = 0; i < bn.child1; ++i) todo.push_back(sc->children[bn.child0 + i]);
+            }
+            return 0;
+        }
+        default: bad(RT_ERR_INVALID_ARGUMENT, "unknown node kind " + std::to_string(n.kind)); return 0;
+        }
+    }
+};
+
+static bool is_book1_sphere_list(const rt_scene_desc* sc) {
+    const rt_node& root = sc->nodes[sc->root];
+    if (root.child1 > 65535) return false;
+    for (int i = 0; i < root.child1; ++i) {
+        const rt_node& nd = sc->nodes[sc->children[root.child0 + i]];
+        if (nd.kind != RT_NODE_SPHERE) return false;
+        const rt_material& m = sc->materials[nd.material];
+        if (m.kind == RT_MAT_LAMBERTIAN) {
+            if (sc->textures[m.texture].kind != RT_TEX_SOLID) return false;
+        } else if (m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
+            return false;
+        }
+    }
+    return true;
+}
+
+static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
+    std::vector<MaterialDev> mats((size_t)sc->n_materials);
+    for (int i = 0; i < sc->n_materials; ++i) {
+        const rt_material& m = sc->materials[i];
+        MaterialDev md{};
+        md.kind = m.kind;
+        md.tex = m.texture;
+        md.param = m.param;
+        md.ax = m.albedo[0];
+        md.ay = m.albedo[1];
+        md.az = m.albedo[2];
+        if (m.kind == RT_MAT_LAMBERTIAN && m.texture >= 0 && sc->textures[m.texture].kind == RT_TEX_SOLID) {
+            md.ax = sc->textures[m.texture].p[0];
+            md.ay = sc->textures[m.texture].p[1];
+            md.az = sc->textures[m.texture].p[2];
+        }
+        mats[i] = md;
+    }
+    return mats;
+}
+
+static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
+    const rt_node& root = sc->nodes[sc->root];
+    const int n = root.child1;
+    const int n_pairs = (n + 1) / 2;
+    std::vector<SpherePair> screen((size_t)std::max(1, n_pairs));
+    std::vector<SphereExact> exact((size_t)std::max(1, n));
+    std::vector<int32_t> material_of((size_t)std::max(1, n));
+    for (auto& s : screen) {  // the pad of an odd list never yields a candidate: q = -huge
+        for (int h = 0; h < 2; ++h) {
+            s.cx[h] = s.cy[h] = s.cz[h] = 0.0f;
+            s.k[h] = 3.0e38f;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const rt_node& nd = sc->nodes[sc->children[root.child0 + i]];
+        const double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
+        exact[i] = SphereExact{cx, cy, cz, r};
+        material_of[i] = nd.material;
+        const double cc = cx * cx + cy * cy + cz * cz, rr = r * r;
+        const double k = cc - rr - 0x1p-18 * (cc + rr);
+        // round k toward -inf so the float image never shrinks the margin
+        float kf = (float)k;
+        if ((double)kf > k) kf = std::nextafterf(kf, -INFINITY);
+        SpherePair& sp = screen[i / 2];
+        sp.cx[i & 1] = (float)cx;
+        sp.cy[i & 1] = (float)cy;
+        sp.cz[i & 1] = (float)cz;
+        sp.k[i & 1] = kf;
+    }
+    const std::vector<MaterialDev> mats = device_materials(sc);
+
+    SphereListDev& S = ctx->spheres;
+    S = SphereListDev{};
+    int rc;
+    if ((rc = to_device(ctx, screen, &S.screen)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, exact, &S.exact)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, material_of, &S.material_of)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, mats, &S.materials)) != RT_OK) return rc;
+    S.n = n;
+    S.n_full_groups = n / SCREEN_GROUP;
+    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
+    S.sky_mode = sc->sky_mode;
+    for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
+    ctx->path = PATH_SPHERE_LIST;
+    return RT_OK;
+}
+
+static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphCheck& chk) {
+    std::vector<SceneNode> nodes((size_t)sc->n_nodes);
+    std::vector<double> extra;
+    for (int i = 0; i < sc->n_nodes; ++i) {
+        const rt_node& n = sc->nodes[i];
+        SceneNode d{};
+        d.kind = n.kind;
+        d.a = d.b = d.c = -1;
+        switch (n.kind) {
+        case RT_NODE_SPHERE:
+            d.a = n.material;
+            for (int k = 0; k < 4; ++k) d.p[k] = n.p[k];
+            break;
+        case RT_NODE_MOVING_SPHERE:
+            d.a = n.material;
+            for (int k = 0; k < 6; ++k) d.p[k] = n.p[k];
+            d.c = (int32_t)extra.size();
+            extra.push_back(n.p[6]);
+            extra.push_back(n.p[7]);
+            extra.push_back(n.p[8]);
+            break;
+        case RT_NODE_XY_RECT:
+        case RT_NODE_XZ_RECT:
+        case RT_NODE_YZ_RECT:
+            d.a = n.material;
+            for (int k = 0; k < 5; ++k) d.p[k] = n.p[k];
+            break;
+        case RT_NODE_LIST:
+        case RT_NODE_BOX:
+            d.a = n.child0;
+            d.b = n.child1;
+            break;
+        case RT_NODE_BVH:
+            d.a = n.child0;
+            d.b = n.child1;
+            for (int k = 0; k < 6; ++k) d.p[k] = n.p[k];
+            break;
+        case RT_NODE_TRANSLATE:
+            d.a = n.child0;
+            for (int k = 0; k < 3; ++k) d.p[k] = n.p[k];
+            break;
+        case RT_NODE_ROTATE_Y:
+            d.a = n.child0;
+            d.p[0] = n.p[0];
+            d.p[1] = n.p[1];
+            break;
+        case RT_NODE_MEDIUM:
+            d.a = n.material;
+            d.b = n.child0;
+            d.p[0] = n.p[0];
+            break;
+        default: break;  // unreachable nodes of unknown kind are never visited
+        }
+        nodes[i] = d;
+    }
+    std::vector<int32_t> children(sc->children, sc->children + sc->n_children);
+    const std::vector<MaterialDev> mats = device_materials(sc);
+    std::vector<TextureDev> texs((size_t)sc->n_textures);
+    for (int i = 0; i < sc->n_textures; ++i) {
+        const rt_texture& t = sc->textures[i];
+        TextureDev d{};
+        d.kind = t.kind;
+        d.a = t.a;
+        d.b = t.b;
+        for (int k = 0; k < 4; ++k) d.p[k] = t.p[k];
+        texs[i] = d;
+    }
+    std::vector<rt_perlin> perlins(sc->perlins, sc->perlins + sc->n_perlins);
+    std::vector<ImageDev> images((size_t)sc->n_images);
+    for (int i = 0; i < sc->n_images; ++i) {
+        const rt_image& im = sc->images[i];
+        images[i] = ImageDev{im.width, im.height, nullptr};
+        if (im.rgb && im.width > 0 && im.height > 0) {
+            std::vector<uint8_t> bytes(im.rgb, im.rgb + (size_t)3 * im.width * im.height);
+            const uint8_t* d = nullptr;
+            int rc = to_device(ctx, bytes, &d);
+            if (rc != RT_OK) return rc;
+            images[i].rgb = d;
+        }
+    }
+
+    SceneDev& G = ctx->graph;
+    G = SceneDev{};
+    int rc;
+    if ((rc = to_device(ctx, nodes, &G.nodes)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, children, &G.children)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, chk.parent_xf, &G.parent_xf)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, chk.top_of, &G.top_of)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, extra, &G.extra)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, mats, &G.materials)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, texs, &G.textures)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, perlins, &G.perlins)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, images, &G.images)) != RT_OK) return rc;
+    G.root = sc->root;
+    G.n_nodes = sc->n_nodes;
+    G.sky_mode = sc->sky_mode;
+    for (int c = 0; c < 3; ++c) G.background[c] = sc->background[c];
+    ctx->path = PATH_GRAPH;
+    return RT_OK;
+}
+
 extern "C" {
 
 int rt_get_device_count(void) {
@@ -88,15 +435,6 @@ const char* rt_error_string(int code) {
 }
 
 const char* rt_last_error_detail(const rt_context* ctx) { return ctx ? ctx->detail.c_str() : g_create_detail.c_str(); }
-
-static void free_scene(rt_context* ctx) {
-    (void)hipFree(ctx->d_screen);
-    (void)hipFree(ctx->d_exact);
-    (void)hipFree(ctx->d_material_of);
-    (void)hipFree(ctx->d_materials);
-    ctx->d_screen = ctx->d_exact = ctx->d_material_of = ctx->d_materials = nullptr;
-    ctx->have_scene = false;
-}
 
 int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     if (!out) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out is null");
@@ -127,10 +465,11 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
         rt_context_destroy(ctx);
         return rc;
     }
-    ctx->blocks_per_cu = render_spheres_blocks_per_cu();
+    ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu();
+    ctx->blocks_per_cu_scene = render_scene_blocks_per_cu();
     if (const char* s = std::getenv("RT_BLOCKS_PER_CU")) {
         int v = std::atoi(s);
-        if (v >= 1 && v <= 8) ctx->blocks_per_cu = v;
+        if (v >= 1 && v <= 8) ctx->blocks_override = v;
     }
     *out = ctx;
     return RT_OK;
@@ -150,109 +489,32 @@ void rt_context_destroy(rt_context* ctx) {
     delete ctx;
 }
 
-// Validate the graph and, for a root list made of spheres only with book-1 materials, build
-// the two device images of the list.
 int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!sc || sc->abi_version != RT_ABI_VERSION) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "scene null or abi_version mismatch");
     if (sc->n_nodes <= 0 || !sc->nodes || sc->root < 0 || sc->root >= sc->n_nodes)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad node array / root");
-    const rt_node& root = sc->nodes[sc->root];
-    if (root.kind != RT_NODE_LIST) return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "root must be a hittable_list");
-    if (root.child1 < 0 || root.child0 < 0 || (int64_t)root.child0 + root.child1 > sc->n_children ||
-        (root.child1 > 0 && !sc->children))
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "root child range outside children[]");
-    const int n = root.child1;
-    if (n > 65535) return fail(ctx, RT_ERR_LIMIT, "more than 65535 objects in a flat list");
+    if (sc->n_nodes > 65535) return fail(ctx, RT_ERR_LIMIT, "more than 65535 nodes");
+    if (sc->nodes[sc->root].kind != RT_NODE_LIST) return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "root must be a hittable_list");
     if (sc->sky_mode != RT_SKY_GRADIENT && sc->sky_mode != RT_SKY_BACKGROUND)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad sky_mode");
 
-    const int n_pairs = (n + 1) / 2;
-    std::vector<SpherePair> screen((size_t)std::max(1, n_pairs));
-    std::vector<SphereExact> exact((size_t)std::max(1, n));
-    std::vector<int32_t> material_of((size_t)std::max(1, n));
-    for (auto& s : screen) {  // the pad of an odd list never yields a candidate: q = -huge
-        for (int h = 0; h < 2; ++h) {
-            s.cx[h] = s.cy[h] = s.cz[h] = 0.0f;
-            s.k[h] = 3.0e38f;
-        }
-    }
-    for (int i = 0; i < n; ++i) {
-        const int ni = sc->children[root.child0 + i];
-        if (ni < 0 || ni >= sc->n_nodes) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "child index out of range");
-        const rt_node& nd = sc->nodes[ni];
-        if (nd.kind != RT_NODE_SPHERE)
-            return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "object " + std::to_string(i) + ": only spheres are supported in this build");
-        if (nd.material < 0 || nd.material >= sc->n_materials || !sc->materials)
-            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "material index out of range");
-        const double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
-        exact[i] = SphereExact{cx, cy, cz, r};
-        material_of[i] = nd.material;
-        const double cc = cx * cx + cy * cy + cz * cz, rr = r * r;
-        const double k = cc - rr - 0x1p-18 * (cc + rr);
-        // round k toward -inf so the float image never shrinks the margin
-        float kf = (float)k;
-        if ((double)kf > k) kf = std::nextafterf(kf, -INFINITY);
-        SpherePair& sp = screen[i / 2];
-        sp.cx[i & 1] = (float)cx;
-        sp.cy[i & 1] = (float)cy;
-        sp.cz[i & 1] = (float)cz;
-        sp.k[i & 1] = kf;
-    }
-    std::vector<MaterialDev> mats((size_t)std::max(1, sc->n_materials));
-    for (int i = 0; i < sc->n_materials; ++i) {
-        const rt_material& m = sc->materials[i];
-        MaterialDev md{};
-        md.kind = m.kind;
-        md.param = m.param;
-        switch (m.kind) {
-        case RT_MAT_LAMBERTIAN: {
-            if (m.texture < 0 || m.texture >= sc->n_textures || !sc->textures)
-                return fail(ctx, RT_ERR_INVALID_ARGUMENT, "lambertian without a texture");
-            const rt_texture& t = sc->textures[m.texture];
-            if (t.kind != RT_TEX_SOLID)
-                return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "only solid_color textures are supported in this build");
-            md.ax = t.p[0];
-            md.ay = t.p[1];
-            md.az = t.p[2];
-            break;
-        }
-        case RT_MAT_METAL:
-            md.ax = m.albedo[0];
-            md.ay = m.albedo[1];
-            md.az = m.albedo[2];
-            break;
-        case RT_MAT_DIELECTRIC: break;
-        default:
-            return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "material kind " + std::to_string(m.kind) + " is not supported in this build");
-        }
-        mats[i] = md;
-    }
+    GraphCheck chk;
+    chk.sc = sc;
+    chk.parent_xf.assign((size_t)sc->n_nodes, -1);
+    chk.top_of.assign((size_t)sc->n_nodes, -1);
+    chk.visited.assign((size_t)sc->n_nodes, 0);
+    const int stack_need = 1 + chk.walk(sc->root, -1, 0, -1);
+    if (chk.code != RT_OK) return fail(ctx, chk.code, chk.error);
+    if (stack_need > STACK_CAP)
+        return fail(ctx, RT_ERR_LIMIT, "traversal needs " + std::to_string(stack_need) + " stack slots, limit " + std::to_string(STACK_CAP));
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    HIP_TRY(ctx, hipMalloc(&ctx->d_screen, screen.size() * sizeof(SpherePair)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_exact, exact.size() * sizeof(SphereExact)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_material_of, material_of.size() * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_materials, mats.size() * sizeof(MaterialDev)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_screen, screen.data(), screen.size() * sizeof(SpherePair), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_exact, exact.data(), exact.size() * sizeof(SphereExact), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_material_of, material_of.data(), material_of.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
-
-    SphereListDev& S = ctx->scene;
-    S.n = n;
-    S.n_full_groups = n / SCREEN_GROUP;
-    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
-    S.screen = (const SpherePair*)ctx->d_screen;
-    S.exact = (const SphereExact*)ctx->d_exact;
-    S.material_of = (const int32_t*)ctx->d_material_of;
-    S.materials = (const MaterialDev*)ctx->d_materials;
-    S.sky_mode = sc->sky_mode;
-    for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
-    ctx->have_scene = true;
-    return RT_OK;
+    int rc = (!ctx->force_graph && is_book1_sphere_list(sc)) ? upload_sphere_list(ctx, sc) : upload_graph(ctx, sc, chk);
+    if (rc != RT_OK) free_scene(ctx);
+    return rc;
 }
 
 static void fill_camera(CameraDev& C, const rt_camera_desc* cam) {
@@ -272,7 +534,7 @@ static void fill_camera(CameraDev& C, const rt_camera_desc* cam) {
 static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!cam || !p) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null camera or params");
-    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not succeeded on this context");
+    if (ctx->path == PATH_NONE) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not succeeded on this context");
     if (p->width < 2 || p->height < 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "width and height must be >= 2 (the reference divides by W-1, H-1)");
     if ((int64_t)p->width * p->height > (int64_t)1 << 28) return fail(ctx, RT_ERR_LIMIT, "more than 2^28 pixels");
     if (p->sample_begin < 0 || p->sample_count < 0 || (int64_t)p->sample_begin + p->sample_count > (int64_t)1 << 30)
@@ -297,27 +559,14 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // depth <= 0: every sample is black
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    RenderArgs A{};
-    A.scene = ctx->scene;
-    fill_camera(A.cam, cam);
-    A.width = p->width;
-    A.height = p->height;
-    A.sample_begin = p->sample_begin;
-    A.sample_count = p->sample_count;
-    A.max_depth = p->max_depth;
-    A.chunk = chunk_for(p);
-    const int64_t chunks = ((int64_t)p->sample_count + A.chunk - 1) / A.chunk;
+    const int chunk = chunk_for(p);
+    const int64_t chunks = ((int64_t)p->sample_count + chunk - 1) / chunk;
     const int64_t items = chunks * p->width * p->height;
     if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
-    A.n_items = (uint32_t)items;
-    A.key0 = (uint32_t)p->seed;
-    A.key1 = (uint32_t)(p->seed >> 32);
-    A.exact_only = (ctx->exact_only || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
-    A.accum = d_accum_fixed;
-    A.item_counter = ctx->d_counter;
-    A.stats = ctx->d_stats;
-
-    int blocks = ctx->num_cus * ctx->blocks_per_cu;
+    const bool spheres = ctx->path == PATH_SPHERE_LIST;
+    int per_cu = spheres ? ctx->blocks_per_cu_spheres : ctx->blocks_per_cu_scene;
+    if (ctx->blocks_override) per_cu = ctx->blocks_override;
+    int blocks = ctx->num_cus * per_cu;
     const int64_t max_useful = (items + 255) / 256;
     if (blocks > max_useful) blocks = (int)max_useful;
     if (blocks < 1) blocks = 1;
@@ -338,7 +587,42 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         e1 = ctx->ev_pool[2 * ctx->ev_used + 1];
     }
     if (e0) HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    HIP_TRY(ctx, launch_render_spheres(A, blocks, ctx->stream));
+    if (spheres) {
+        RenderArgs A{};
+        A.scene = ctx->spheres;
+        fill_camera(A.cam, cam);
+        A.width = p->width;
+        A.height = p->height;
+        A.sample_begin = p->sample_begin;
+        A.sample_count = p->sample_count;
+        A.max_depth = p->max_depth;
+        A.chunk = chunk;
+        A.n_items = (uint32_t)items;
+        A.key0 = (uint32_t)p->seed;
+        A.key1 = (uint32_t)(p->seed >> 32);
+        A.exact_only = (ctx->exact_only || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
+        A.accum = d_accum_fixed;
+        A.item_counter = ctx->d_counter;
+        A.stats = ctx->d_stats;
+        HIP_TRY(ctx, launch_render_spheres(A, blocks, ctx->stream));
+    } else {
+        SceneRenderArgs A{};
+        A.scene = ctx->graph;
+        fill_camera(A.cam, cam);
+        A.width = p->width;
+        A.height = p->height;
+        A.sample_begin = p->sample_begin;
+        A.sample_count = p->sample_count;
+        A.max_depth = p->max_depth;
+        A.chunk = chunk;
+        A.n_items = (uint32_t)items;
+        A.key0 = (uint32_t)p->seed;
+        A.key1 = (uint32_t)(p->seed >> 32);
+        A.accum = d_accum_fixed;
+        A.item_counter = ctx->d_counter;
+        A.stats = ctx->d_stats;
+        HIP_TRY(ctx, launch_render_scene(A, blocks, ctx->stream));
+    }
     if (e1) {
         HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
         ++ctx->ev_used;
@@ -356,6 +640,12 @@ int rt_context_synchronize(rt_context* ctx) {
 int rt_context_set_exact_only(rt_context* ctx, int on) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     ctx->exact_only = on != 0;
+    return RT_OK;
+}
+
+int rt_context_set_force_graph(rt_context* ctx, int on) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    ctx->force_graph = on != 0;
     return RT_OK;
 }
 
@@ -418,7 +708,7 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
 int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int height, int32_t* ids_out) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!cam || !ids_out) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null camera or output");
-    if (!ctx->have_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not succeeded on this context");
+    if (ctx->path == PATH_NONE) return fail(ctx, RT_ERR_NO_SCENE, "rt_scene_upload has not succeeded on this context");
     if (width < 2 || height < 2 || (int64_t)width * height > (int64_t)1 << 28)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad image size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -431,14 +721,24 @@ int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int heig
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ids, elems * sizeof(int32_t)));
         ctx->ids_elems = elems;
     }
-    FirstHitArgs A{};
-    A.scene = ctx->scene;
-    fill_camera(A.cam, cam);
-    A.width = width;
-    A.height = height;
-    A.exact_only = ctx->exact_only ? 1 : 0;
-    A.ids = ctx->d_ids;
-    HIP_TRY(ctx, launch_first_hit_spheres(A, ctx->stream));
+    if (ctx->path == PATH_SPHERE_LIST) {
+        FirstHitArgs A{};
+        A.scene = ctx->spheres;
+        fill_camera(A.cam, cam);
+        A.width = width;
+        A.height = height;
+        A.exact_only = ctx->exact_only ? 1 : 0;
+        A.ids = ctx->d_ids;
+        HIP_TRY(ctx, launch_first_hit_spheres(A, ctx->stream));
+    } else {
+        SceneFirstHitArgs A{};
+        A.scene = ctx->graph;
+        fill_camera(A.cam, cam);
+        A.width = width;
+        A.height = height;
+        A.ids = ctx->d_ids;
+        HIP_TRY(ctx, launch_first_hit_scene(A, ctx->stream));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ids_out, ctx->d_ids, elems * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;

@@ -20,8 +20,8 @@ namespace rtd {
 //                B1/vec3.h:145-151), try TRY_TIME = [shutter time, -, -, -]
 //   site 1+b     ray segment b: try k = [x, y, z, -] of the k-th unit-sphere rejection attempt
 //                (B1/vec3.h:114-120) or [Schlick draw, -, -, -] for a dielectric
-//                (B1/material.h:72); try TRY_MEDIUM+m = the m-th constant_medium draw
-//                (B2/constant_medium.h:48) met while intersecting the segment.
+//                (B1/material.h:72); try TRY_MEDIUM+i = the draw of the constant_medium with node
+//                index i (B2/constant_medium.h:48) made while intersecting the segment.
 // A draw is (word >> 1) * 2^-31: the 31-bit grid of rand()/(RAND_MAX+1.0) (B1/rtweekend.h:24-27).
 constexpr uint32_t TRY_TIME = 0x80000000u;
 constexpr uint32_t TRY_MEDIUM = 0x40000000u;

@@ -25,7 +25,7 @@ struct SphereExact {
 };
 struct MaterialDev {
     int32_t kind;  // RT_MAT_*
-    int32_t pad;
+    int32_t tex;   // texture index of lambertian / diffuse_light / isotropic (general scenes), else -1
     double ax, ay, az;  // albedo (lambertian with a solid texture, metal)
     double param;       // fuzz / ir
 };
@@ -72,6 +72,68 @@ struct FirstHitArgs {
     int32_t exact_only;
     int32_t* ids;
 };
+
+// ---- device layout of a general scene graph (book 2/3 worlds)
+//
+// One SceneNode per rt_node, same index, so that ids (first-hit gate, Philox keys of media) need no
+// translation.  64 bytes: four 16-byte vector loads per visit.  The graph, materials, textures, Perlin
+// tables and images of the largest reference scene total about 0.5 MB: resident in every XCD's L2.
+struct SceneNode {
+    int32_t kind;  // RT_NODE_*
+    int32_t a;     // sphere/rect/medium: material; LIST/BOX: first child slot; BVH: left; instance/medium: child
+    int32_t b;     // LIST/BOX: child count; BVH: right; medium: boundary node
+    int32_t c;     // moving sphere: index of {time0, time1, radius} in extra[]
+    double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | translate: offset
+                   // | rotate_y: sin, cos | medium: neg_inv_density
+};
+struct TextureDev {
+    int32_t kind, a, b, pad;  // RT_TEX_*; checker: even, odd; noise: perlin index; image: image index or -1
+    double p[4];              // solid: colour; noise: scale
+};
+struct ImageDev {
+    int32_t width, height;
+    const uint8_t* rgb;
+};
+struct SceneDev {
+    int32_t root;
+    int32_t n_nodes;
+    const SceneNode* nodes;
+    const int32_t* children;
+    const int32_t* parent_xf;  // per node: enclosing translate/rotate_y node, or -1
+    const int32_t* top_of;     // per node: index within the root list of the top-level object containing it
+    const double* extra;
+    const MaterialDev* materials;
+    const TextureDev* textures;
+    const rt_perlin* perlins;
+    const ImageDev* images;
+    int32_t sky_mode;
+    double background[3];
+};
+constexpr int STACK_CAP = 40;   // traversal stack slots per lane (uint32 each, in LDS)
+constexpr int XF_DEPTH_CAP = 4;  // nested translate / rotate_y levels
+
+struct SceneRenderArgs {
+    SceneDev scene;
+    CameraDev cam;
+    int32_t width, height;
+    int32_t sample_begin, sample_count;
+    int32_t max_depth;
+    int32_t chunk;
+    uint32_t n_items;
+    uint32_t key0, key1;
+    int64_t* accum;
+    uint32_t* item_counter;
+    uint64_t* stats;
+};
+struct SceneFirstHitArgs {
+    SceneDev scene;
+    CameraDev cam;
+    int32_t width, height;
+    int32_t* ids;
+};
+hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream);
+hipError_t launch_first_hit_scene(const SceneFirstHitArgs& args, hipStream_t stream);
+int render_scene_blocks_per_cu();
 
 // Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.
 hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream);

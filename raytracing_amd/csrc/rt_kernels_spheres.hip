@@ -26,6 +26,7 @@
 // so the rendered numbers are those of an all-double renderer.
 #include "rt_device_common.h"
 #include "rt_internal.h"
+#include "rt_render_common.h"
 
 namespace rtd {
 
@@ -183,54 +184,6 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
     return h;
 }
 
-// ---------------------------------------------------------------- camera
-// camera::get_ray (B1/camera.h:34-39) for pixel column i, reference row j, sample `sample`.
-__device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int i, int j, uint32_t pixel,
-                                           uint32_t sample, uint32_t k0, uint32_t k1, d3& o, d3& d) {
-    u32x4 w = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
-    const double s = (i + u01(w.x)) / (W - 1);  // B1/RayTracing.cpp:120-121
-    const double t = (j + u01(w.y)) / (H - 1);
-    double px = u_range(w.z, -1, 1), py = u_range(w.w, -1, 1);
-    for (uint32_t k = 1; px * px + py * py + 0.0 * 0.0 >= 1; ++k) {  // random_in_unit_disk
-        w = philox4x32_10(pixel, sample, 0u, k, k0, k1);
-        px = u_range(w.x, -1, 1);
-        py = u_range(w.y, -1, 1);
-    }
-    const double rdx = C.lens_radius * px, rdy = C.lens_radius * py;
-    const d3 cu{C.u[0], C.u[1], C.u[2]}, cv{C.v[0], C.v[1], C.v[2]};
-    const d3 offset = rdx * cu + rdy * cv;
-    const d3 origin{C.origin[0], C.origin[1], C.origin[2]};
-    const d3 llc{C.llc[0], C.llc[1], C.llc[2]};
-    const d3 hor{C.horizontal[0], C.horizontal[1], C.horizontal[2]};
-    const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
-    o = origin + offset;
-    d = llc + s * hor + t * ver - origin - offset;
-}
-
-// random_in_unit_sphere, B1/vec3.h:114-120, for the lanes with need == true.
-__device__ __forceinline__ d3 random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t site,
-                                                    uint32_t k0, uint32_t k1) {
-    d3 p{0, 0, 0};
-    for (uint32_t k = 0; need; ++k) {
-        const u32x4 w = philox4x32_10(pixel, sample, site, k, k0, k1);
-        p = d3{u_range(w.x, -1, 1), u_range(w.y, -1, 1), u_range(w.z, -1, 1)};
-        if (!(len2(p) >= 1)) need = false;
-    }
-    return p;
-}
-
-__device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  // B1/material.h:83-88
-    double r0 = (1 - ref_idx) / (1 + ref_idx);
-    r0 = r0 * r0;
-    const double x = 1 - cosine;
-    const double x2 = x * x;
-    return r0 + (1 - r0) * (x2 * x2 * x);  // pow(x, 5) by multiplication (<= 2 ulp from libm pow)
-}
-
-__device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
-    __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ---------------------------------------------------------------- render kernel
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 4
@@ -373,13 +326,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             }
             if (done) {
                 const d3 c = T * L_end;
-                if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) {
-                    fx += __double2ll_rn(c.x * ACCUM_SCALE);
-                    fy += __double2ll_rn(c.y * ACCUM_SCALE);
-                    fz += __double2ll_rn(c.z * ACCUM_SCALE);
-                } else {
-                    ++n_bad;
-                }
+                add_sample(c, fx, fy, fz, n_bad);
                 active = false;
                 ++s_cur;
             }

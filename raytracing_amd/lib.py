@@ -51,6 +51,8 @@ def load():
     L.rt_context_synchronize.argtypes = [ctx_p]
     L.rt_context_set_exact_only.restype = C.c_int
     L.rt_context_set_exact_only.argtypes = [ctx_p, C.c_int]
+    L.rt_context_set_force_graph.restype = C.c_int
+    L.rt_context_set_force_graph.argtypes = [ctx_p, C.c_int]
     L.rt_context_take_stats.restype = C.c_int
     L.rt_context_take_stats.argtypes = [ctx_p, C.POINTER(abi.rt_stats)]
     L.rt_first_hit.restype = C.c_int
@@ -72,7 +74,8 @@ def load():
 
 EXPORTED_SYMBOLS = [
     "rt_get_device_count", "rt_context_create", "rt_context_destroy", "rt_scene_upload", "rt_render",
-    "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_take_stats",
+    "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_set_force_graph",
+    "rt_context_take_stats",
     "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
 ]
 
@@ -146,6 +149,10 @@ class Context:
 
     def set_exact_only(self, on: bool):
         self._check(self._L.rt_context_set_exact_only(self._h, int(bool(on))), "rt_context_set_exact_only")
+
+    def set_force_graph(self, on: bool):
+        """Takes effect at the next upload()."""
+        self._check(self._L.rt_context_set_force_graph(self._h, int(bool(on))), "rt_context_set_force_graph")
 
     def render(self, cam, params):
         """-> (double colour sums [H,W,3], stats dict)"""
