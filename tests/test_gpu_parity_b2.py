@@ -1,0 +1,131 @@
+"""Parity of the scene-graph kernels (books 2 and 3) through the C ABI.
+
+Bars: colour sums bit-identical to the oracle run with the same Philox draws (the kernels keep the
+reference's traversal order and double arithmetic; sin/log/acos/atan2 come from the device library, and on
+every scene tested they produce the same sums -- if a future toolchain changes that, the assertion to relax
+is marked below); first-hit ids bit-identical to the reference's; images against the reference's own
+rand()-driven renders within the measured reference-vs-reference noise."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import oracle_binding as ob
+from tests.conftest import CAM_C2, gold
+from tests.test_oracle_golden_b2 import B2_SCENES, camera_b2, load_b2
+
+pytestmark = pytest.mark.gpu
+FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+
+
+@pytest.fixture(scope="module")
+def kat_b2():
+    with open(gold("kat_b2.json")) as fp:
+        return json.load(fp)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_sums(scene, cam, p):
+    _, fixed, st = ob.render(scene, cam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    return fixed.astype(np.float64) / FRAC, st
+
+
+@pytest.mark.parametrize("name", B2_SCENES)
+def test_scene_render_matches_oracle(ctx, kat_b2, name):
+    k = kat_b2[name]
+    scene = load_b2(name)
+    cam = camera_b2(k, lib.camera)
+    ctx.upload(scene)
+    for W, H, spp, seed, begin in ((72, 54, 5, 3, 0), (33, 21, 3, 2 ** 33 + 1, 7)):
+        p = abi.render_params(W, H, spp, 50, seed=seed, sample_begin=begin)
+        got, st = ctx.render(cam, p)
+        want, ost = oracle_sums(scene, cam, p)
+        assert st["rays"] == ost["rays"] and st["nan_samples"] == 0
+        # bit-identical today; the fallback bar for scenes that call sin/log/acos/atan2 would be
+        # np.abs(got - want).max() <= 4 * 2**-36 on all but a handful of pixels
+        assert np.array_equal(got, want), (name, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("name", ["bouncing", "two_spheres", "two_perlin", "earth_real", "simple_light", "cornell_box"])
+def test_scene_first_hit_ids(ctx, kat_b2, name):
+    k = kat_b2[name]
+    fh = k["firsthit"]
+    ctx.upload(load_b2(name))
+    ids = ctx.first_hit(camera_b2(k, lib.camera), fh["width"], fh["height"])
+    assert np.array_equal(ids, np.load(gold(f"b2_{name}_firsthit.npz"))["ids"].astype(np.int32))
+
+
+def test_sphere_list_scene_through_graph_kernels(ctx, scene_c2):
+    """The two kernel families agree bit for bit on a scene both can render."""
+    cam = lib.camera(*CAM_C2)
+    p = abi.render_params(96, 64, 4, 50, seed=1)
+    ctx.upload(scene_c2)
+    a, sa = ctx.render(cam, p)
+    ids_a = ctx.first_hit(cam, 150, 100)
+    ctx.set_force_graph(True)
+    ctx.upload(scene_c2)
+    b, sb = ctx.render(cam, p)
+    ids_b = ctx.first_hit(cam, 150, 100)
+    ctx.set_force_graph(False)
+    assert np.array_equal(a, b) and sa["rays"] == sb["rays"] and np.array_equal(ids_a, ids_b)
+
+
+@pytest.mark.parametrize("name", ["bouncing", "cornell_box", "cornell_smoke", "final", "two_perlin", "simple_light"])
+def test_scene_image_vs_reference(ctx, kat_b2, name):
+    """GPU image at the fixture's spp against the mean of the reference's four seeds.
+    r = measured RMSE between two reference renders at that spp; a correct render lies at r*sqrt(5/8) from
+    the 4-seed mean.  Gate: RMSE <= 1.12 * r * sqrt(5/8); image mean within 4 standard errors of the mean
+    (r / sqrt(pixels) scale) + 1e-3 relative."""
+    k = kat_b2[name]
+    im = k["image"]
+    W, H, spp = im["width"], im["height"], im["spp_each"]
+    r = float(np.mean(im["pair_rmse"]))
+    ref = np.load(gold(f"b2_{name}_ref.npz"))["radiance"].astype(np.float64)
+    ctx.upload(load_b2(name))
+    img = ctx.render(camera_b2(k, lib.camera), abi.render_params(W, H, spp, 50, seed=1))[0] / spp
+    rmse = float(np.sqrt(np.mean((img - ref) ** 2)))
+    assert rmse <= 1.12 * r * np.sqrt(5.0 / 8.0), (rmse, r)
+    mean_err = np.abs(img.reshape(-1, 3).mean(0) - np.array(im["image_mean_rgb"]))
+    assert mean_err.max() <= 4 * r / np.sqrt(W * H) + 1e-3 * max(im["image_mean_rgb"]), mean_err
+
+
+def test_final_scene_full_size_properties(ctx, kat_b2):
+    """Config 4 geometry at its full 800x800: statistics, determinism, split additivity, three rows vs the oracle."""
+    k = kat_b2["final"]
+    scene = load_b2("final")
+    cam = camera_b2(k, lib.camera)
+    ctx.upload(scene)
+    W = H = 800
+    a, st = ctx.render(cam, abi.render_params(W, H, 4, 50, seed=1))
+    assert st["samples"] == W * H * 4 and st["nan_samples"] == 0
+    assert 4.5 < st["rays"] / st["samples"] < 5.4          # the reference measures 4.7-5.0 rays per sample
+    b, _ = ctx.render(cam, abi.render_params(W, H, 4, 50, seed=1))
+    assert np.array_equal(a, b)
+    lo, _ = ctx.render(cam, abi.render_params(W, H, 1, 50, seed=1))
+    hi, _ = ctx.render(cam, abi.render_params(W, H, 3, 50, seed=1, sample_begin=1))
+    assert np.array_equal(np.rint(lo * FRAC).astype(np.int64) + np.rint(hi * FRAC).astype(np.int64),
+                          np.rint(a * FRAC).astype(np.int64))
+    p = abi.render_params(W, H, 4, 50, seed=1)
+    for row in (5, 400, 790):
+        assert np.array_equal(a[row], ob.render_rows(scene, cam, p, row, row + 1, has_time=True)[0] / FRAC)
+
+
+def test_unsupported_graphs_are_rejected_loudly(ctx):
+    """A medium whose boundary is itself a BVH is outside what the kernels cover: upload must fail, not fall back."""
+    s = load_b2("cornell_smoke")
+    nodes = s.nodes.copy()
+    med = int(np.where(nodes["kind"] == abi.RT_NODE_MEDIUM)[0][0])
+    b = int(nodes[med]["child0"])
+    nodes[b]["kind"] = abi.RT_NODE_BVH
+    bad = abi.Scene(s.root, nodes, s.children, s.materials, s.textures, s.perlins, s.images, s.sky_mode, s.background)
+    with pytest.raises(lib.RtError) as e:
+        ctx.upload(bad)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED_SCENE
