@@ -107,8 +107,7 @@ int dump_scene(const hittable_list& world, const char* path) {
                 for (int c = 0; c < 3; ++c) t.p[c] = l->albedo[c];
                 texs.push_back(t);
                 rm.kind = RT_MAT_LAMBERTIAN;
-                rm.texture = (int)texs.size() - 1;
-                for (int c = 0; c < 3; ++c) rm.albedo[c] = l->albedo[c];
+                rm.texture = (int)texs.size() - 1;  // the colour lives in the texture (as in book 2)
             } else if (auto* me = dynamic_cast<const metal*>(m)) {
                 rm.kind = RT_MAT_METAL;
                 for (int c = 0; c < 3; ++c) rm.albedo[c] = me->albedo[c];
