@@ -17,6 +17,7 @@
 
 #include "raytracing_amd.h"
 #include "rt_internal.h"
+#include "rt_render_common.h"
 
 using namespace rtd;
 
@@ -542,14 +543,14 @@ static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const r
     return RT_OK;
 }
 
-static int chunk_for(const rt_render_params* p) {
-    int chunk = 8;
+// Longest run of samples of one pixel handed to a lane as one work item (RT_ITEM_SAMPLES overrides).
+static int item_cap_for(const rt_render_params*) {
+    int cap = 8;
     if (const char* s = std::getenv("RT_ITEM_SAMPLES")) {
         int v = std::atoi(s);
-        if (v >= 1) chunk = v;
+        if (v >= 1) cap = v;
     }
-    if (chunk > p->sample_count) chunk = p->sample_count;
-    return chunk < 1 ? 1 : chunk;
+    return cap;
 }
 
 int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed) {
@@ -559,9 +560,9 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // depth <= 0: every sample is black
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    const int chunk = chunk_for(p);
-    const int64_t chunks = ((int64_t)p->sample_count + chunk - 1) / chunk;
-    const int64_t items = chunks * p->width * p->height;
+    const int item_cap = item_cap_for(p);
+    const ItemPlan plan = make_item_plan(p->sample_count, item_cap);
+    const int64_t items = (int64_t)plan.levels * p->width * p->height;
     if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
     const bool spheres = ctx->path == PATH_SPHERE_LIST;
     int per_cu = spheres ? ctx->blocks_per_cu_spheres : ctx->blocks_per_cu_scene;
@@ -596,7 +597,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;
-        A.chunk = chunk;
+        A.item_cap = item_cap;
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);
@@ -614,7 +615,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;
-        A.chunk = chunk;
+        A.item_cap = item_cap;
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);

@@ -56,7 +56,7 @@ struct RenderArgs {
     int32_t width, height;
     int32_t sample_begin, sample_count;
     int32_t max_depth;
-    int32_t chunk;          // samples of one pixel that form a work item
+    int32_t item_cap;       // longest run of samples of one pixel that forms a work item (see ItemPlan)
     uint32_t n_items;       // number of work items
     uint32_t key0, key1;    // Philox key
     int32_t exact_only;     // 1: skip the float screen, test every sphere in double (validation)
@@ -118,7 +118,7 @@ struct SceneRenderArgs {
     int32_t width, height;
     int32_t sample_begin, sample_count;
     int32_t max_depth;
-    int32_t chunk;
+    int32_t item_cap;
     uint32_t n_items;
     uint32_t key0, key1;
     int64_t* accum;

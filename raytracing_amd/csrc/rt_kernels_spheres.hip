@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     uint16_t* list = s_list[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
-    const int s_last = A.sample_begin + A.sample_count;
+    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
 
     // per-lane path state
     bool active = false, has_item = false, retired = false;
@@ -241,9 +241,10 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             if (need && rank < avail) {
                 const uint32_t item = batch_next + rank;
                 pixel = item % npix;
-                const int chunk_idx = (int)(item / npix);
-                s_cur = A.sample_begin + chunk_idx * A.chunk;
-                s_end = min(s_cur + A.chunk, s_last);
+                int first, count;
+                item_run(plan, (int)(item / npix), first, count);
+                s_cur = A.sample_begin + first;
+                s_end = s_cur + count;
                 fx = fy = fz = 0;
                 has_item = true;
                 need = false;

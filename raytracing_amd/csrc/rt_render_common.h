@@ -56,6 +56,36 @@ __device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
 }
 
 
+// Work items.  The samples [0, N) of a pixel are cut into `levels` runs: K runs of `cap` samples, then the
+// remaining R = N - K*cap (cap <= R < 2*cap when N >= cap) halved repeatedly: R - R/2, R/2 - R/4, ..., 1.
+// Item m is run (m / npix) of pixel (m % npix), so the queue hands out every pixel's long runs first and
+// one-sample runs last: few atomics per pixel, and a fine-grained tail at the end of the launch.
+struct ItemPlan {
+    int32_t cap, K, R, levels;
+};
+__host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap) {
+    ItemPlan p;
+    p.cap = cap < 1 ? 1 : cap;
+    p.K = n_samples / p.cap - 1;
+    if (p.K < 0) p.K = 0;
+    p.R = n_samples - p.K * p.cap;
+    int bits = 0;
+    for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
+    p.levels = p.K + bits;
+    return p;
+}
+// samples [first, first + count) of run `level`, relative to the first sample of the call
+__device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& first, int& count) {
+    if (level < p.K) {
+        first = level * p.cap;
+        count = p.cap;
+    } else {
+        const int g = level - p.K;
+        first = p.K * p.cap + p.R - (p.R >> g);
+        count = (p.R >> g) - (p.R >> (g + 1));
+    }
+}
+
 // Converts one sample colour to 2^-RT_ACCUM_FRAC_BITS fixed point and adds it; a non-finite colour is
 // dropped and counted (the reference would carry the NaN into its image).
 __device__ __forceinline__ void add_sample(d3 c, int64_t& fx, int64_t& fy, int64_t& fz, uint32_t& n_bad) {
