@@ -93,11 +93,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    # Rehearsal on a one-GPU box: RT_BENCH_SHARE_GPU=1 puts every rank on device 0 and RT_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the normal path is one GPU per rank over nccl.
+    if os.environ.get("RT_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_reduce = os.environ.get("RT_BENCH_FORCE_REDUCE") == "1"   # rehearsal: collectives even with one rank
+    if world > 1 or force_reduce:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     scene_path = os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc")
     scene = abi.load_scene(scene_path)
@@ -106,7 +115,8 @@ def main():
     W, H, spp = args.width, args.height, args.spp
 
     # One slot per frame in flight: its own HIP stream, library context (the scene is tiny: one copy per slot)
-    # and accumulation buffer.  Frame k runs entirely on slot k % n: zero -> render kernel -> all-reduce.
+    # and accumulation buffer.  Frame k runs entirely on slot k % n: zero -> render kernel -> all-reduce
+    # (frame.FramePipeline orders the all-reduce of frame k-1 after the launch of frame k).
     n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
     slots = []
     for _ in range(n_slots):
@@ -117,33 +127,59 @@ def main():
             buf = torch.zeros((H, W, 3), dtype=torch.int64, device=dev)
         slots.append((s, c, buf))
 
-    reduce_fn = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if world > 1 else None
+    verbose = os.environ.get("RT_BENCH_VERBOSE") == "1"
+    if verbose:
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_STALL_S", "30")), exit=True)
 
-    def step(k):
-        s, c, buf = slots[k % n_slots]
+    def say(msg):
+        if verbose:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-        def render_fn(begin, count, b):
-            c.render_device(cam, abi.render_params(W, H, count, args.depth, seed=1 + k, sample_begin=begin), b.data_ptr())
+    def reduce_fn(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-        with torch.cuda.stream(s):
-            frame.render_frame(render_fn, buf, spp, rank, world, reduce_fn)
+    class Slot:
+        def __init__(self, s, c, buf):
+            self.s, self.c, self.accum = s, c, buf
+
+        def stream(self):
+            return torch.cuda.stream(self.s)
+
+        def drain(self):
+            self.s.synchronize()
+
+        def render(self, begin, count, accum, k):
+            self.c.render_device(cam, abi.render_params(W, H, count, args.depth, seed=1 + k, sample_begin=begin),
+                                 accum.data_ptr())
+
+    pipe = frame.FramePipeline([Slot(*t) for t in slots], spp, rank, world, reduce_fn if world > 1 else None)
+    if force_reduce:
+        pipe.world, pipe.all_reduce = max(world, 2), reduce_fn
+    step = pipe.submit
 
     def fence():
+        pipe.flush()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    say("contexts ready")
     for k in range(args.warmup):
         step(k)
+        say(f"warm-up step {k} enqueued")
     fence()
+    say("warm-up done")
     for _, c, _ in slots:
         c.take_stats()  # drop warm-up statistics
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    say("timed steps enqueued")
     fence()
     dt = time.perf_counter() - t0
+    say("timed region done")
     st = {"samples": 0, "rays": 0, "nan_samples": 0, "kernel_ms": 0.0, "kernel_launches": 0}
     for _, c, _ in slots:
         one = c.take_stats()
@@ -193,7 +229,7 @@ def main():
 
     for _, c, _ in slots:
         c.close()
-    if world > 1:
+    if world > 1 or force_reduce:
         dist.destroy_process_group()
 
 

@@ -34,3 +34,57 @@ def render_frame(render_fn, accum, spp: int, rank: int = 0, world: int = 1, all_
     if world > 1:
         all_reduce(accum)
     return accum
+
+
+class FramePipeline:
+    """Frames in flight on several slots, each slot = (accumulation buffer, stream, renderer).
+
+    Frame k runs on slot k % n.  `submit(k)` zeroes the slot's buffer and enqueues this rank's share of
+    frame k; with several ranks it then issues the all-reduce of the PREVIOUS frame (n > 1) or of this
+    frame (n == 1), after draining that frame's stream on the host.  Draining first means the collective
+    never waits on an unfinished kernel through a cross-stream event, and with n > 1 the host wait
+    happens while the next frame is already queued on another stream, so the long-path tail of one
+    frame and its all-reduce overlap the start of the next.  `flush()` issues what is still pending.
+
+    A slot needs: `.accum` (int64 tensor), `.render(begin, count, accum, k)` (enqueues work that adds),
+    `.stream()` (context manager making the slot's stream current) and `.drain()` (host wait for the
+    slot's stream).  Every rank must call submit/flush in the same order.
+    """
+
+    def __init__(self, slots, spp: int, rank: int = 0, world: int = 1, all_reduce=None):
+        if not slots:
+            raise ValueError("need at least one slot")
+        if world > 1 and all_reduce is None:
+            raise ValueError("several ranks need an all_reduce")
+        self.slots = list(slots)
+        self.spp, self.rank, self.world, self.all_reduce = spp, rank, world, all_reduce
+        self.begin, self.count = sample_range(spp, rank, world)
+        self._pending = []          # slot indices whose frame is rendered (enqueued) but not yet reduced
+
+    def _reduce(self, i):
+        slot = self.slots[i]
+        slot.drain()
+        with slot.stream():
+            self.all_reduce(slot.accum)
+
+    def submit(self, k: int):
+        i = k % len(self.slots)
+        if i in self._pending:      # only with a caller that skips frames: never overwrite an unreduced frame
+            self.flush()
+        slot = self.slots[i]
+        with slot.stream():
+            slot.accum.zero_()
+            if self.count > 0:
+                slot.render(self.begin, self.count, slot.accum, k)
+        if self.world > 1:
+            while self._pending:
+                self._reduce(self._pending.pop(0))
+            if len(self.slots) == 1:
+                self._reduce(i)
+            else:
+                self._pending.append(i)
+        return slot.accum
+
+    def flush(self):
+        while self._pending:
+            self._reduce(self._pending.pop(0))

@@ -57,6 +57,57 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+class _CpuSlot:
+    """A FramePipeline slot without a GPU: the oracle renders immediately, streams are no-ops."""
+
+    def __init__(self, scene, cam, log):
+        self.accum = torch.zeros((H, W, 3), dtype=torch.int64)
+        self.scene, self.cam, self.log = scene, cam, log
+
+    def stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def drain(self):
+        self.log.append("drain")
+
+    def render(self, begin, count, accum, k):
+        self.log.append(f"render{k}")
+        p = abi.render_params(W, H, count, 50, seed=SEED + k, sample_begin=begin)
+        _, fixed, _ = ob.render(self.scene, self.cam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=2)
+        accum += torch.from_numpy(fixed)
+
+
+def _pipeline_worker(rank, world, port, out_dir, n_slots, n_frames):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = abi.load_scene(gold("scene_c2.rtsc"))
+        cam = ob.camera(*CAM_C2)
+        log = []
+
+        def reduce_fn(t):
+            log.append("reduce")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+        slots = [_CpuSlot(scene, cam, log) for _ in range(n_slots)]
+        pipe = frame.FramePipeline(slots, SPP, rank, world, reduce_fn)
+        frames = {}
+        for k in range(n_frames):
+            if k >= n_slots:        # the slot about to be reused holds the finished frame k - n_slots
+                frames[k - n_slots] = slots[k % n_slots].accum.clone()
+            pipe.submit(k)
+        pipe.flush()
+        for k in range(max(0, n_frames - n_slots), n_frames):
+            frames[k] = slots[k % n_slots].accum.clone()
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.stack([frames[k].numpy() for k in range(n_frames)]))
+        with open(os.path.join(out_dir, f"log{rank}.txt"), "w") as f:
+            f.write(" ".join(log))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -76,3 +127,39 @@ def test_split_frame_equals_unsplit_frame(world, tmp_path):
     # every rank can tone-map on its own: identical 8-bit images
     sums = whole.numpy().astype(np.float64) / 2.0 ** abi.RT_ACCUM_FRAC_BITS
     assert ob.write_color(sums, SPP).shape == (H, W, 3)
+
+
+@pytest.mark.parametrize("n_slots", [1, 2])
+def test_pipelined_frames_equal_unsplit_frames(n_slots, tmp_path):
+    """Frames in flight on one or two slots over two ranks: every frame equals the single-process frame,
+    each collective is issued after a host drain of its slot, and with two slots the all-reduce of frame
+    k-1 comes after the launch of frame k."""
+    world, n_frames = 2, 3
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), str(tmp_path), n_slots, n_frames), nprocs=world, join=True)
+    scene = abi.load_scene(gold("scene_c2.rtsc"))
+    cam = ob.camera(*CAM_C2)
+    for k in range(n_frames):
+        whole = torch.zeros((H, W, 3), dtype=torch.int64)
+        p = abi.render_params(W, H, SPP, 50, seed=SEED + k)
+        _, fixed, _ = ob.render(scene, cam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=2)
+        for r in range(world):
+            got = np.load(tmp_path / f"rank{r}.npy")[k]
+            assert np.array_equal(got, fixed), f"frame {k} on rank {r} differs from the single-process frame"
+    log = (tmp_path / "log0.txt").read_text().split()
+    if n_slots == 1:
+        assert log == ["render0", "drain", "reduce", "render1", "drain", "reduce", "render2", "drain", "reduce"]
+    else:
+        assert log == ["render0", "render1", "drain", "reduce", "render2", "drain", "reduce", "drain", "reduce"]
+
+
+def test_pipeline_single_rank_needs_no_collective():
+    log = []
+    scene = abi.load_scene(gold("scene_c2.rtsc"))
+    pipe = frame.FramePipeline([_CpuSlot(scene, ob.camera(*CAM_C2), log)], SPP)
+    pipe.submit(0)
+    pipe.flush()
+    assert log == ["render0"]
+    with pytest.raises(ValueError):
+        frame.FramePipeline([], SPP)
+    with pytest.raises(ValueError):
+        frame.FramePipeline([object()], SPP, 0, 2, None)
