@@ -266,10 +266,11 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
     const rt_node& root = sc->nodes[sc->root];
     const int n = root.child1;
     const int n_pairs = (n + 1) / 2;
-    std::vector<SpherePair> screen((size_t)std::max(1, n_pairs));
+    const int n_chunks = std::max(1, (n_pairs + 255) / 256);
+    std::vector<SpherePair> screen((size_t)n_chunks * 256);  // whole chunks: the sparse walk reads 4 pairs per lane
     std::vector<SphereExact> exact((size_t)std::max(1, n));
     std::vector<int32_t> material_of((size_t)std::max(1, n));
-    for (auto& s : screen) {  // the pad of an odd list never yields a candidate: q = -huge
+    for (auto& s : screen) {  // padding never yields a candidate: q = -huge
         for (int h = 0; h < 2; ++h) {
             s.cx[h] = s.cy[h] = s.cz[h] = 0.0f;
             s.k[h] = 3.0e38f;
@@ -303,6 +304,7 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
     S.n = n;
     S.n_full_groups = n / SCREEN_GROUP;
     S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
+    S.n_chunks = n_chunks;
     S.sky_mode = sc->sky_mode;
     for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
     ctx->path = PATH_SPHERE_LIST;
@@ -436,6 +438,10 @@ const char* rt_error_string(int code) {
 }
 
 const char* rt_last_error_detail(const rt_context* ctx) { return ctx ? ctx->detail.c_str() : g_create_detail.c_str(); }
+
+#ifdef RT_TAIL_PROBE
+static uint64_t* g_probe = nullptr;
+#endif
 
 int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     if (!out) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out is null");
@@ -605,6 +611,15 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.accum = d_accum_fixed;
         A.item_counter = ctx->d_counter;
         A.stats = ctx->d_stats;
+#ifdef RT_TAIL_PROBE
+        {   // debug build: per-wave timestamps of the LAST launch, dumped by rt_context_take_stats
+            static uint64_t* d_probe = nullptr;
+            if (!d_probe) HIP_TRY(ctx, hipMalloc((void**)&d_probe, 8 * sizeof(uint64_t) * 65536));
+            HIP_TRY(ctx, hipMemsetAsync(d_probe, 0, 8 * sizeof(uint64_t) * 65536, ctx->stream));
+            A.probe = blocks * 4 <= 65536 ? d_probe : nullptr;
+            g_probe = d_probe;
+        }
+#endif
         HIP_TRY(ctx, launch_render_spheres(A, blocks, ctx->stream));
     } else {
         SceneRenderArgs A{};
@@ -653,6 +668,19 @@ int rt_context_set_force_graph(rt_context* ctx, int on) {
 int rt_context_take_stats(rt_context* ctx, rt_stats* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+#ifdef RT_TAIL_PROBE
+    if (g_probe) {
+        if (const char* path = std::getenv("RT_TAIL_PROBE_FILE")) {
+            std::vector<uint64_t> h(8 * 65536);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipMemcpy(h.data(), g_probe, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(path, "wb")) {
+                std::fwrite(h.data(), sizeof(uint64_t), h.size(), f);
+                std::fclose(f);
+            }
+        }
+    }
+#endif
     uint64_t h[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(h), ctx->stream));

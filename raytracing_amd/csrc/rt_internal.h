@@ -37,6 +37,7 @@ struct SphereListDev {
     int32_t n;         // spheres in list order (= object ids)
     int32_t n_full_groups;  // n / SCREEN_GROUP: groups screened by the unrolled loop
     int32_t n_tail_pairs;   // pairs of the last, partial group (0..15); an odd sphere is padded
+    int32_t n_chunks;       // 256-pair chunks of the screen image (padded with never-hit pairs to a whole chunk)
     const SpherePair* screen;
     const SphereExact* exact;
     const int32_t* material_of;
@@ -63,6 +64,9 @@ struct RenderArgs {
     int64_t* accum;         // [3*width*height] fixed point, added to with atomics
     uint32_t* item_counter; // work-queue head, zeroed before launch
     uint64_t* stats;        // [4]: samples, rays, non-finite samples, overflow rays
+#ifdef RT_TAIL_PROBE
+    uint64_t* probe;  // debug build only: 8 words per wave (timestamps and iteration counts)
+#endif
 };
 
 struct FirstHitArgs {

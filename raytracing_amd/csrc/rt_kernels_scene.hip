@@ -430,73 +430,29 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
 
-    bool active = false, has_item = false, retired = false;
-    uint32_t pixel = 0, bounce = 0;
-    int s_cur = 0, s_end = 0, depth_left = 0;
-    int64_t fx = 0, fy = 0, fz = 0;
+    bool active = false;
+    uint32_t bounce = 0;
+    int depth_left = 0;
     Ray r{d3{0, 0, 0}, d3{0, 0, 1}};
     d3 T{1, 1, 1};
     double tm = 0.0;
-    uint32_t batch_next = 0, batch_end = 0;
-    bool queue_empty = false;
+    LaneWork w{};
+    WaveWork wq{};
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum};
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0;
 
     for (;;) {
-        if (!active && has_item && s_cur == s_end) {
-            atomic_add_i64(A.accum + 3ull * pixel + 0, fx);
-            atomic_add_i64(A.accum + 3ull * pixel + 1, fy);
-            atomic_add_i64(A.accum + 3ull * pixel + 2, fz);
-            has_item = false;
-        }
-        bool need = !active && !retired && !has_item;
-        while (ballot(need) != 0ull) {
-            if (batch_next == batch_end) {
-                if (!queue_empty) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(A.item_counter, 64u);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (base >= A.n_items) {
-                        queue_empty = true;
-                    } else {
-                        batch_next = base;
-                        batch_end = min(base + 64u, A.n_items);
-                    }
-                }
-                if (queue_empty) {
-                    if (need) retired = true;
-                    need = false;
-                    break;
-                }
-            }
-            const uint64_t m = ballot(need);
-            const uint32_t rank = rank_below(m);
-            const uint32_t avail = batch_end - batch_next;
-            if (need && rank < avail) {
-                const uint32_t item = batch_next + rank;
-                pixel = item % npix;
-                int first, count;
-                item_run(plan, (int)(item / npix), first, count);
-                s_cur = A.sample_begin + first;
-                s_end = s_cur + count;
-                fx = fy = fz = 0;
-                has_item = true;
-                need = false;
-            }
-            batch_next += min((uint32_t)__popcll(m), avail);
-        }
-        if (ballot(!retired) == 0ull) break;
-
-        if (!active && has_item) {
-            r = primary_ray(A.cam, A.width, A.height, pixel, (uint32_t)s_cur, A.key0, A.key1, tm);
+        if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
+        if (!active && w.has_item) {
+            r = primary_ray(A.cam, A.width, A.height, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, tm);
             T = d3{1, 1, 1};
             depth_left = A.max_depth;
             bounce = 0;
             active = true;
             ++n_samples;
         }
-
         const bool on = active;
-        const RngCtx g{pixel, (uint32_t)s_cur, 1u + bounce, A.key0, A.key1};
+        const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
         const Hit h = trace(S, r, tm, on, stack, lane, g);
 
         if (on) {
@@ -556,9 +512,9 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
                 }
             }
             if (done) {
-                add_sample(T * L_end, fx, fy, fz, n_bad);
+                add_sample(T * L_end, w.fx, w.fy, w.fz, n_bad);
                 active = false;
-                ++s_cur;
+                ++w.s_cur;
             }
         }
     }

@@ -84,9 +84,8 @@ typedef __attribute__((address_space(4))) SpherePair ConstSpherePair;
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Screens the two spheres of *s; appends their sign bits (first sphere first) to mask.
-__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const ConstSpherePair* s, uint32_t mask) {
-    const f2 cx{s->cx[0], s->cx[1]}, cy{s->cy[0], s->cy[1]}, cz{s->cz[0], s->cz[1]}, k{s->k[0], s->k[1]};
+// Screens two spheres given as packed operands; appends their sign bits (first sphere first) to mask.
+__device__ __forceinline__ uint32_t screen_pair_ops(const ScreenRay& r, f2 cx, f2 cy, f2 cz, f2 k, uint32_t mask) {
     f2 hb = pk_fma(cx, r.ndx, r.od);
     hb = pk_fma(cy, r.ndy, hb);
     hb = pk_fma(cz, r.ndz, hb);
@@ -98,6 +97,32 @@ __device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const ConstS
     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
     return __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
 }
+// The pair *s read through the constant address space (scalar loads, SGPR-pair operands).
+__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const ConstSpherePair* s, uint32_t mask) {
+    return screen_pair_ops(r, f2{s->cx[0], s->cx[1]}, f2{s->cy[0], s->cy[1]}, f2{s->cz[0], s->cz[1]}, f2{s->k[0], s->k[1]}, mask);
+}
+// The pair p held in this lane's registers.
+__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const SpherePair& p, uint32_t mask) {
+    return screen_pair_ops(r, f2{p.cx[0], p.cx[1]}, f2{p.cy[0], p.cy[1]}, f2{p.cz[0], p.cz[1]}, f2{p.k[0], p.k[1]}, mask);
+}
+
+__device__ __forceinline__ f2 splat_from_lane(f2 v, int src_lane) {
+    const float f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v.x), src_lane));
+    return f2{f, f};
+}
+
+// Sparse waves.  When few lanes hold a ray (the end of a launch), walking all spheres with all 64 lanes
+// wastes most of the wave.  Instead the wave turns by 90 degrees: lane t keeps spheres 8t..8t+7 of a
+// 512-sphere chunk in registers, the rays are taken one at a time (their screening constants broadcast
+// from the owning lane), every lane screens its 8 spheres against that ray with the same packed
+// operations, and the 8 result bits go to byte t of the ray's row in LDS -- 64 bytes = the same 512-bit
+// candidate mask the dense walk produces, at ~1/40 of its cost per ray.
+#ifndef RT_SPARSE_MAX_RAYS
+#define RT_SPARSE_MAX_RAYS 32
+#endif
+constexpr int SPARSE_MAX_RAYS = RT_SPARSE_MAX_RAYS;  // dense walk: ~10k cycles per wave; this path: ~300 per ray and chunk
+constexpr int ROW_WORDS = 17;        // 16 mask words per ray + 1 pad (bank spread)
+constexpr int SPARSE_CHUNK_PAIRS = 256;
 
 // ---------------------------------------------------------------- exact pass
 struct Hit {
@@ -129,7 +154,7 @@ __device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d
 // of the wave (wave-level loops); lanes with on == false take no part in the result.
 // `list` = this wave's CAND_CAP*64 uint16 slots in LDS.
 __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, bool on, bool exact_only,
-                                           uint16_t* list, int lane, uint32_t& overflow_count) {
+                                           uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count) {
     const double a = len2(d);
     const double t_min = 0.001;  // B1/RayTracing.cpp:17
     Hit h{__builtin_inf(), -1};
@@ -143,6 +168,47 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
 
     const ScreenRay sr = screen_prepare(o, d, a);
     uint32_t cnt = 0;
+    const uint64_t on_mask = ballot(on);
+    if (__popcll(on_mask) <= SPARSE_MAX_RAYS) {
+        for (int c = 0; c < S.n_chunks; ++c) {
+            const SpherePair* mine = S.screen + (size_t)c * SPARSE_CHUNK_PAIRS + (size_t)lane * 4;
+            const SpherePair p0 = mine[0], p1 = mine[1], p2 = mine[2], p3 = mine[3];
+            for (uint64_t m = on_mask; m != 0ull; m &= m - 1ull) {
+                const int src = __builtin_ctzll(m);
+                ScreenRay rl;
+                rl.ndx = splat_from_lane(sr.ndx, src);
+                rl.ndy = splat_from_lane(sr.ndy, src);
+                rl.ndz = splat_from_lane(sr.ndz, src);
+                rl.p2ox = splat_from_lane(sr.p2ox, src);
+                rl.p2oy = splat_from_lane(sr.p2oy, src);
+                rl.p2oz = splat_from_lane(sr.p2oz, src);
+                rl.od = splat_from_lane(sr.od, src);
+                rl.e = splat_from_lane(sr.e, src);
+                uint32_t mk = screen_pair(rl, p0, 0u);
+                mk = screen_pair(rl, p1, mk);
+                mk = screen_pair(rl, p2, mk);
+                mk = screen_pair(rl, p3, mk);
+                ((uint8_t*)rows)[src * (ROW_WORDS * 4) + lane] = (uint8_t)~mk;  // bit 7 = sphere 8*lane
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int g = 0; g < 2 * SPARSE_CHUNK_PAIRS / SCREEN_GROUP; ++g) {
+                // bytes 4g..4g+3 of the row, first byte on top: bit 31 = first sphere of the group
+                uint32_t cand = on ? __builtin_bswap32(rows[lane * ROW_WORDS + g]) : 0u;
+                while (ballot(cand != 0u) != 0ull) {
+                    if (cand != 0u) {
+                        const int z = __clz((int)cand);
+                        cand &= ~(0x80000000u >> z);
+                        if (cnt < (uint32_t)CAND_CAP)
+                            list[cnt * 64 + lane] = (uint16_t)(c * 2 * SPARSE_CHUNK_PAIRS + g * SCREEN_GROUP + z);
+                        ++cnt;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
     // The screen image is immutable for the whole launch: address it through the constant
     // address space so that the wave-uniform reads become scalar loads (SGPR operands).
     const ConstSpherePair* sp = (const ConstSpherePair*)S.screen;
@@ -169,6 +235,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
             }
         }
     }
+    }
 
     const bool overflow = cnt > (uint32_t)CAND_CAP;
     const uint32_t my_n = overflow ? 0u : cnt;
@@ -190,88 +257,62 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
 #endif
 __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A) {
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
+    __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
+    uint32_t* rows = s_rows[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
 
     // per-lane path state
-    bool active = false, has_item = false, retired = false;
-    uint32_t pixel = 0, bounce = 0;
-    int s_cur = 0, s_end = 0, depth_left = 0;
-    int64_t fx = 0, fy = 0, fz = 0;
+    bool active = false;
+    uint32_t bounce = 0;
+    int depth_left = 0;
     d3 o{0, 0, 0}, d{0, 0, 1}, T{1, 1, 1};
-    // wave-uniform work-queue window
-    uint32_t batch_next = 0, batch_end = 0;
-    bool queue_empty = false;
+    LaneWork w{};
+    WaveWork wq{};
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum};
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0, n_overflow = 0;
+#ifdef RT_TAIL_PROBE
+    const uint64_t pr_t0 = wall_clock64();
+    uint64_t pr_tq = 0, pr_iters = 0, pr_iters_q = 0, pr_lanes_q = 0, pr_lanes = 0;
+#endif
 
     for (;;) {
         // ---- refill: finish items, take new ones, start the next sample
-        if (!active && has_item && s_cur == s_end) {
-            atomic_add_i64(A.accum + 3ull * pixel + 0, fx);
-            atomic_add_i64(A.accum + 3ull * pixel + 1, fy);
-            atomic_add_i64(A.accum + 3ull * pixel + 2, fz);
-            has_item = false;
-        }
-        bool need = !active && !retired && !has_item;
-        while (ballot(need) != 0ull) {
-            if (batch_next == batch_end) {
-                if (!queue_empty) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(A.item_counter, 64u);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (base >= A.n_items) {
-                        queue_empty = true;
-                    } else {
-                        batch_next = base;
-                        batch_end = min(base + 64u, A.n_items);
-                    }
-                }
-                if (queue_empty) {
-                    if (need) retired = true;
-                    need = false;
-                    break;
-                }
-            }
-            const uint64_t m = ballot(need);
-            const uint32_t rank = rank_below(m);
-            const uint32_t avail = batch_end - batch_next;
-            if (need && rank < avail) {
-                const uint32_t item = batch_next + rank;
-                pixel = item % npix;
-                int first, count;
-                item_run(plan, (int)(item / npix), first, count);
-                s_cur = A.sample_begin + first;
-                s_end = s_cur + count;
-                fx = fy = fz = 0;
-                has_item = true;
-                need = false;
-            }
-            batch_next += min((uint32_t)__popcll(m), avail);
-        }
-        if (ballot(!retired) == 0ull) break;
-
-        if (!active && has_item) {
-            const int i = (int)(pixel % (uint32_t)A.width);
-            const int j = A.height - 1 - (int)(pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
-            camera_ray(A.cam, A.width, A.height, i, j, pixel, (uint32_t)s_cur, A.key0, A.key1, o, d);
+        if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
+        if (!active && w.has_item) {
+            const int i = (int)(w.pixel % (uint32_t)A.width);
+            const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
+            camera_ray(A.cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, o, d);
             T = d3{1, 1, 1};
             depth_left = A.max_depth;
             bounce = 0;
             active = true;
             ++n_samples;
         }
-
         // ---- closest hit (all lanes together)
         const bool on = active;
-        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, lane, n_overflow);
+#ifdef RT_TAIL_PROBE
+        {
+            const uint64_t na = (uint64_t)__popcll(ballot(on));
+            ++pr_iters;
+            pr_lanes += na;
+            if (wq.dry) {
+                if (pr_tq == 0) pr_tq = wall_clock64();
+                ++pr_iters_q;
+                pr_lanes_q += na;
+            }
+        }
+#endif
+        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, rows, lane, n_overflow);
 
         // ---- shade
         if (on) {
             ++n_rays;
-            const uint32_t sample = (uint32_t)s_cur;
+            const uint32_t sample = (uint32_t)w.s_cur;
+            const uint32_t pixel = w.pixel;
             const uint32_t site = 1u + bounce;
             bool done = false;
             d3 L_end{0, 0, 0};
@@ -327,13 +368,26 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             }
             if (done) {
                 const d3 c = T * L_end;
-                add_sample(c, fx, fy, fz, n_bad);
+                add_sample(c, w.fx, w.fy, w.fz, n_bad);
                 active = false;
-                ++s_cur;
+                ++w.s_cur;
             }
         }
     }
 
+#ifdef RT_TAIL_PROBE
+    if (lane == 0 && A.probe) {
+        uint64_t* w = A.probe + 8ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        w[0] = pr_t0;
+        w[1] = pr_tq;
+        w[2] = wall_clock64();
+        w[3] = pr_iters;
+        w[4] = pr_iters_q;
+        w[5] = pr_lanes;
+        w[6] = pr_lanes_q;
+        w[7] = 1;
+    }
+#endif
     // ---- statistics: one atomic per counter per wave
     uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad, v3 = n_overflow;
 #pragma unroll
@@ -355,8 +409,10 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
 // One lane per pixel centre; definition in raytracing_amd.h (rt_first_hit).
 __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A) {
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
+    __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
+    uint32_t* rows = s_rows[threadIdx.x >> 6];
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
     const bool on = pixel < npix;
@@ -375,7 +431,7 @@ __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A)
     const d3 o = origin + offset;
     const d3 d = llc + s * hor + t * ver - origin - offset;
     uint32_t ovf = 0;
-    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, lane, ovf);
+    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, rows, lane, ovf);
     if (on) A.ids[pixel] = h.id;
 }
 

@@ -86,6 +86,92 @@ __device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& firs
     }
 }
 
+// ---------------------------------------------------------------- work source of a persistent wave
+//
+// Items of the plan above are handed out in batches of 64 from one device-wide atomic counter.  Once the
+// queue is dry, a lane that still holds unstarted samples of its item gives them, one at a time, to
+// idle lanes of its own wave (register exchange, no memory traffic): pixels differ tenfold in cost, and
+// without this the end of a launch waits for one lane to walk through the rest of a heavy item.
+// Polling a device-wide give-back queue instead was tried and is far slower: thousands of waves
+// reading one counter every trip serialise on that address.
+struct WorkQueues {
+    uint32_t* counter;  // head of the item queue, zeroed before launch
+    uint32_t n_items;
+    int64_t* accum;
+};
+struct LaneWork {
+    bool has_item;
+    uint32_t pixel;
+    int32_t s_cur, s_end;  // next sample to start / end of the run
+    int64_t fx, fy, fz;    // fixed-point sums of the finished samples of the item
+};
+struct WaveWork {
+    uint32_t batch_next, batch_end;
+    bool dry;  // queue exhausted (wave-uniform)
+};
+
+// One refill step for the wave; `active` = lane has a path in flight.  Returns false when the wave is done.
+// Afterwards a lane with has_item && !active must start sample s_cur.
+__device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan& plan, uint32_t npix, int32_t sample_begin,
+                                            int lane, bool active, LaneWork& w, WaveWork& q) {
+    if (!active && w.has_item && w.s_cur == w.s_end) {
+        atomic_add_i64(Q.accum + 3ull * w.pixel + 0, w.fx);
+        atomic_add_i64(Q.accum + 3ull * w.pixel + 1, w.fy);
+        atomic_add_i64(Q.accum + 3ull * w.pixel + 2, w.fz);
+        w.has_item = false;
+    }
+    bool need = !active && !w.has_item;
+    while (!q.dry && ballot(need) != 0ull) {
+        if (q.batch_next == q.batch_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(Q.counter, 64u);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= Q.n_items) {
+                q.dry = true;
+                break;
+            }
+            q.batch_next = base;
+            q.batch_end = min(base + 64u, Q.n_items);
+        }
+        const uint64_t m = ballot(need);
+        const uint32_t rank = rank_below(m);
+        const uint32_t avail = q.batch_end - q.batch_next;
+        if (need && rank < avail) {
+            const uint32_t item = q.batch_next + rank;
+            w.pixel = item % npix;
+            int first, count;
+            item_run(plan, (int)(item / npix), first, count);
+            w.s_cur = sample_begin + first;
+            w.s_end = w.s_cur + count;
+            w.fx = w.fy = w.fz = 0;
+            w.has_item = true;
+            need = false;
+        }
+        q.batch_next += min((uint32_t)__popcll(m), avail);
+    }
+    if (!q.dry) return true;
+
+    // ---- queue dry: hand unstarted samples (from the end of a run) to idle lanes of this wave
+    for (;;) {
+        const bool can_give = w.has_item && w.s_end - w.s_cur > 1;
+        const uint64_t givers = ballot(can_give), takers = ballot(need);
+        if (givers == 0ull || takers == 0ull) break;
+        const int g = __builtin_ctzll(givers), t = __builtin_ctzll(takers);
+        if (lane == g) --w.s_end;
+        const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)w.pixel, g);
+        const int32_t smp = __builtin_amdgcn_readlane(w.s_end, g);
+        if (lane == t) {
+            w.pixel = px;
+            w.s_cur = smp;
+            w.s_end = smp + 1;
+            w.fx = w.fy = w.fz = 0;
+            w.has_item = true;
+            need = false;
+        }
+    }
+    return ballot(active || w.has_item) != 0ull;
+}
+
 // Converts one sample colour to 2^-RT_ACCUM_FRAC_BITS fixed point and adds it; a non-finite colour is
 // dropped and counted (the reference would carry the NaN into its image).
 __device__ __forceinline__ void add_sample(d3 c, int64_t& fx, int64_t& fy, int64_t& fz, uint32_t& n_bad) {

@@ -162,6 +162,43 @@ def test_list_lengths_around_group_boundaries(ctx, n):
     assert np.array_equal(ctx.first_hit(cam, 45, 30), ob.first_hit(s, cam, 45, 30))
 
 
+@pytest.mark.parametrize("n", [513, 600, 1100])
+def test_lists_longer_than_one_sparse_chunk(ctx, n):
+    """Waves with few rays screen 512-sphere chunks sphere-parallel; lists of two and three chunks, on a
+    frame large enough to start dense and on one so small that every wave is sparse from the start."""
+    rng = np.random.default_rng(n)
+    sph = [(0, -1000, 0, 1000, 0)]
+    for _ in range(n - 1):
+        x, z = rng.uniform(-14, 14, 2)
+        sph.append((x, 0.2, z, 0.2, int(rng.integers(0, 4))))
+    mats = [("lambertian", (0.5, 0.6, 0.4)), ("metal", (0.8, 0.7, 0.6), 0.2), ("dielectric", 1.5),
+            ("lambertian", (0.9, 0.2, 0.2))]
+    s = make_sphere_scene(sph, mats)
+    cam = lib.camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 40.0, 1.5, 0.05, 10.0)
+    ctx.upload(s)
+    for W, H, spp in ((48, 32, 3), (7, 5, 4)):
+        p = abi.render_params(W, H, spp, 15, seed=n)
+        got, _ = ctx.render(cam, p)
+        want, _ = oracle_sums(s, cam, p)
+        assert np.array_equal(got, want)
+    assert np.array_equal(ctx.first_hit(cam, 45, 30), ob.first_hit(s, cam, 45, 30))
+
+
+@pytest.mark.parametrize("W,H,spp,cap", [(2, 2, 40, "8"), (7, 5, 9, "8"), (3, 2, 129, "64"), (1200, 2, 5, "8")])
+def test_small_frames_hand_samples_to_idle_lanes(ctx, scene_c2, monkeypatch, W, H, spp, cap):
+    """Once the item queue is dry, lanes give unstarted samples to idle lanes of their wave and the wave
+    screens sphere-parallel; with fewer pixels than lanes that is the whole launch.  Sums stay those of
+    the oracle bit for bit."""
+    monkeypatch.setenv("RT_ITEM_SAMPLES", cap)
+    cam = lib.camera(*CAM_C2)
+    ctx.upload(scene_c2)
+    p = abi.render_params(W, H, spp, 50, seed=77)
+    got, st = ctx.render(cam, p)
+    want, ost = oracle_sums(scene_c2, cam, p)
+    assert np.array_equal(got, want)
+    assert st["samples"] == W * H * spp and st["rays"] == ost["rays"]
+
+
 def test_candidate_overflow_takes_the_exact_path(ctx):
     """48 nested glass shells: every central ray has more candidates than LDS slots."""
     sph = [(0, 0, 0, 1.0 + 0.05 * k, 0) for k in range(48)]
