@@ -311,6 +311,24 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
     return RT_OK;
 }
 
+// True if box node n has exactly the six sides box::box (B2/box.h:31-38) derives from its corners, in that order,
+// stored as consecutively numbered nodes.  Values are compared bit for bit.
+static bool is_reference_box(const rt_scene_desc* sc, const rt_node& n) {
+    if (n.child1 != 6 || n.child0 < 0 || n.child0 + 6 > sc->n_children) return false;
+    const double x0 = n.p[0], y0 = n.p[1], z0 = n.p[2], x1 = n.p[3], y1 = n.p[4], z1 = n.p[5];
+    const int kinds[6] = {RT_NODE_XY_RECT, RT_NODE_XY_RECT, RT_NODE_XZ_RECT, RT_NODE_XZ_RECT, RT_NODE_YZ_RECT, RT_NODE_YZ_RECT};
+    const double want[6][5] = {{x0, x1, y0, y1, z1}, {x0, x1, y0, y1, z0}, {x0, x1, z0, z1, y1},
+                               {x0, x1, z0, z1, y0}, {y0, y1, z0, z1, x1}, {y0, y1, z0, z1, x0}};
+    const int first = sc->children[n.child0];
+    for (int i = 0; i < 6; ++i) {
+        const int c = sc->children[n.child0 + i];
+        if (c != first + i || c < 0 || c >= sc->n_nodes) return false;
+        const rt_node& r = sc->nodes[c];
+        if (r.kind != kinds[i] || std::memcmp(r.p, want[i], sizeof(want[i])) != 0) return false;
+    }
+    return true;
+}
+
 static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphCheck& chk) {
     std::vector<SceneNode> nodes((size_t)sc->n_nodes);
     std::vector<double> extra;
@@ -342,6 +360,11 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
         case RT_NODE_BOX:
             d.a = n.child0;
             d.b = n.child1;
+            if (n.kind == RT_NODE_BOX && is_reference_box(sc, n)) {
+                d.kind = DEV_NODE_BOX6;
+                d.c = sc->children[n.child0];
+                for (int k = 0; k < 6; ++k) d.p[k] = n.p[k];
+            }
             break;
         case RT_NODE_BVH:
             d.a = n.child0;
@@ -408,6 +431,16 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     G.n_nodes = sc->n_nodes;
     G.sky_mode = sc->sky_mode;
     for (int c = 0; c < 3; ++c) G.background[c] = sc->background[c];
+    // which kernel variant the world needs (a superset is always valid; RT_SCENE_VARIANT=all forces the general one)
+    int features = 0;
+    for (int i = 0; i < sc->n_nodes; ++i) features |= scene_feature_bit_for_node(sc->nodes[i].kind);
+    for (int i = 0; i < sc->n_textures; ++i) features |= scene_feature_bit_for_texture(sc->textures[i].kind);
+    for (int i = 0; i < sc->n_materials; ++i) features |= scene_feature_bit_for_material(sc->materials[i].kind);
+    if (const char* v = std::getenv("RT_SCENE_VARIANT")) {
+        if (std::strcmp(v, "all") == 0) features = ~0;
+    }
+    G.features = features;
+    ctx->blocks_per_cu_scene = render_scene_blocks_per_cu(features);
     ctx->path = PATH_GRAPH;
     return RT_OK;
 }
@@ -473,7 +506,6 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
         return rc;
     }
     ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu();
-    ctx->blocks_per_cu_scene = render_scene_blocks_per_cu();
     if (const char* s = std::getenv("RT_BLOCKS_PER_CU")) {
         int v = std::atoi(s);
         if (v >= 1 && v <= 8) ctx->blocks_override = v;
@@ -614,8 +646,8 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
 #ifdef RT_TAIL_PROBE
         {   // debug build: per-wave timestamps of the LAST launch, dumped by rt_context_take_stats
             static uint64_t* d_probe = nullptr;
-            if (!d_probe) HIP_TRY(ctx, hipMalloc((void**)&d_probe, 8 * sizeof(uint64_t) * 65536));
-            HIP_TRY(ctx, hipMemsetAsync(d_probe, 0, 8 * sizeof(uint64_t) * 65536, ctx->stream));
+            if (!d_probe) HIP_TRY(ctx, hipMalloc((void**)&d_probe, 16 * sizeof(uint64_t) * 65536));
+            HIP_TRY(ctx, hipMemsetAsync(d_probe, 0, 16 * sizeof(uint64_t) * 65536, ctx->stream));
             A.probe = blocks * 4 <= 65536 ? d_probe : nullptr;
             g_probe = d_probe;
         }
@@ -668,10 +700,14 @@ int rt_context_set_force_graph(rt_context* ctx, int on) {
 int rt_context_take_stats(rt_context* ctx, rt_stats* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+#ifdef RT_SCENE_PROBE
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    scene_probe_dump();
+#endif
 #ifdef RT_TAIL_PROBE
     if (g_probe) {
         if (const char* path = std::getenv("RT_TAIL_PROBE_FILE")) {
-            std::vector<uint64_t> h(8 * 65536);
+            std::vector<uint64_t> h(16 * 65536);
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipMemcpy(h.data(), g_probe, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(path, "wb")) {

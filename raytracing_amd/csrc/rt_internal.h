@@ -82,12 +82,15 @@ struct FirstHitArgs {
 // One SceneNode per rt_node, same index, so that ids (first-hit gate, Philox keys of media) need no
 // translation.  64 bytes: four 16-byte vector loads per visit.  The graph, materials, textures, Perlin
 // tables and images of the largest reference scene total about 0.5 MB: resident in every XCD's L2.
+// Device-only node kind: a box whose six sides are those the reference's constructor derives from its corners and are
+// numbered consecutively; the traversal tests the sides from the corners in one step.
+constexpr int DEV_NODE_BOX6 = 64;
 struct SceneNode {
-    int32_t kind;  // RT_NODE_*
+    int32_t kind;  // RT_NODE_* or DEV_NODE_BOX6
     int32_t a;     // sphere/rect/medium: material; LIST/BOX: first child slot; BVH: left; instance/medium: child
     int32_t b;     // LIST/BOX: child count; BVH: right; medium: boundary node
-    int32_t c;     // moving sphere: index of {time0, time1, radius} in extra[]
-    double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | translate: offset
+    int32_t c;     // moving sphere: index of {time0, time1, radius} in extra[]; DEV_NODE_BOX6: node id of the first side
+    double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | box: corners | translate: offset
                    // | rotate_y: sin, cos | medium: neg_inv_density
 };
 struct TextureDev {
@@ -111,6 +114,7 @@ struct SceneDev {
     const rt_perlin* perlins;
     const ImageDev* images;
     int32_t sky_mode;
+    int32_t features;  // F_* bits of rt_kernels_scene.hip the world needs
     double background[3];
 };
 constexpr int STACK_CAP = 40;   // traversal stack slots per lane (uint32 each, in LDS)
@@ -137,7 +141,13 @@ struct SceneFirstHitArgs {
 };
 hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_first_hit_scene(const SceneFirstHitArgs& args, hipStream_t stream);
-int render_scene_blocks_per_cu();
+int render_scene_blocks_per_cu(int features);
+#ifdef RT_SCENE_PROBE
+void scene_probe_dump();  // debug build: prints and clears the traversal counters
+#endif
+int scene_feature_bit_for_node(int node_kind);  // F_* bit a node / texture / material kind needs, 0 if none
+int scene_feature_bit_for_texture(int texture_kind);
+int scene_feature_bit_for_material(int material_kind);
 
 // Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.
 hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream);

@@ -15,6 +15,8 @@
 // the role of the t_max the reference threads through its calls.  Every test is done in double with the
 // reference's operation order, so winner, t, hit point and normal are the reference's, bit for bit.
 // A hit only records (t, node, enclosing instance); the full hit record is rebuilt once, for the winner.
+#include <cstdio>
+
 #include "rt_device_common.h"
 #include "rt_internal.h"
 #include "rt_render_common.h"
@@ -25,7 +27,22 @@ namespace {
 
 // Stack entry: node id in the low 16 bits; high 16 bits = END_XF (leave that instance node) or, for a
 // list / box, the index of the next child to visit (a list occupies one slot however long it is).
-constexpr uint32_t END_XF = 0xFFFFu;
+constexpr uint32_t END_XF = 0xFFFFu;            // leave a rotate_y node
+constexpr uint32_t END_XF_TRANSLATE = 0xFFFEu;  // leave a translate node
+
+// Scene features a kernel variant is compiled for (template parameter F).  A world that has no instances,
+// media, rectangles ... runs a variant without that code: fewer registers (more waves per SIMD to hide
+// the latency of the dependent node loads) and fewer divergent cases in the traversal loop.
+enum : int {
+    F_MOVING = 1,    // moving spheres
+    F_RECT = 2,      // rectangles and boxes
+    F_XF = 4,        // translate / rotate_y instances
+    F_MEDIUM = 8,    // constant media and the isotropic material
+    F_CHECKER = 16,  // checker textures
+    F_NOISE = 32,    // Perlin noise textures
+    F_IMAGE = 64,    // image textures
+    F_ALL = 127,
+};
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
 
 struct Ray {
@@ -51,7 +68,9 @@ __device__ __forceinline__ Ray xf_apply(const SceneNode& n, Ray r) {
 
 // The world ray as seen inside instance node `xf` (-1: the world itself): the enclosing instances'
 // transforms applied outermost first, recomputed from the world ray so that no ray stack is needed.
+template <int F>
 __device__ __forceinline__ Ray ray_in(const SceneDev& S, int xf, Ray world) {
+    if constexpr (!(F & F_XF)) return world;
     int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
     int x = xf;
     if (x >= 0) { c0 = x; x = S.parent_xf[x]; }
@@ -66,7 +85,35 @@ __device__ __forceinline__ Ray ray_in(const SceneDev& S, int xf, Ray world) {
     return r;
 }
 
-// sphere::hit up to the accepted root (B2/sphere.h:42-60).
+// sphere::hit up to the accepted root (B2/sphere.h:42-60), in two steps so that callers that ask twice about the
+// same ray and sphere (constant_medium) share the arithmetic: both roots, then the reference's choice between them.
+struct SphereRoots {
+    bool real;  // discriminant >= 0
+    double near_root, far_root;
+};
+__device__ __forceinline__ SphereRoots sphere_roots(d3 center, double radius, const Ray& r, double a) {
+    const d3 oc = r.o - center;
+    const double half_b = dot(oc, r.d);
+    const double c = len2(oc) - radius * radius;
+    const double discriminant = half_b * half_b - a * c;
+    SphereRoots s{false, 0.0, 0.0};
+    if (discriminant < 0) return s;
+    const double sqrtd = sqrt(discriminant);
+    s.real = true;
+    s.near_root = (-half_b - sqrtd) / a;
+    s.far_root = (-half_b + sqrtd) / a;
+    return s;
+}
+__device__ __forceinline__ bool pick_root(const SphereRoots& s, double t_min, double t_max, double& t) {
+    if (!s.real) return false;
+    double root = s.near_root;
+    if (root < t_min || root > t_max) {
+        root = s.far_root;
+        if (root < t_min || root > t_max) return false;
+    }
+    t = root;
+    return true;
+}
 __device__ __forceinline__ bool hit_sphere(d3 center, double radius, const Ray& r, double a, double t_min, double t_max,
                                            double& t) {
     const d3 oc = r.o - center;
@@ -91,34 +138,66 @@ __device__ __forceinline__ d3 moving_center(const SceneDev& S, const SceneNode& 
     return c0 + ((tm - time0) / (time1 - time0)) * (c1 - c0);
 }
 
-// xy_rect / xz_rect / yz_rect ::hit up to acceptance (B2/aarect.h:28-34, 70-76, 112-118)
-__device__ __forceinline__ bool hit_rect(const SceneNode& n, const Ray& r, double t_min, double t_max, double& t,
-                                         double& ua, double& vb) {
-    const int ka = n.kind == RT_NODE_XY_RECT ? 2 : (n.kind == RT_NODE_XZ_RECT ? 1 : 0);
-    const int aa = n.kind == RT_NODE_YZ_RECT ? 1 : 0;
-    const int ba = n.kind == RT_NODE_XY_RECT ? 1 : 2;
-    const double tt = (n.p[4] - comp(r.o, ka)) / comp(r.d, ka);
+// xy_rect / xz_rect / yz_rect ::hit up to acceptance (B2/aarect.h:28-34, 70-76, 112-118): the plane is axis ka = k,
+// the rectangle spans [a0,a1] on axis aa and [b0,b1] on axis ba.
+__device__ __forceinline__ bool hit_rect_raw(int ka, int aa, int ba, double a0, double a1, double b0, double b1, double k,
+                                             const Ray& r, double t_min, double t_max, double& t, double& ua, double& vb) {
+    const double tt = (k - comp(r.o, ka)) / comp(r.d, ka);
     if (tt < t_min || tt > t_max) return false;
     const double a = comp(r.o, aa) + tt * comp(r.d, aa);
     const double b = comp(r.o, ba) + tt * comp(r.d, ba);
-    if (a < n.p[0] || a > n.p[1] || b < n.p[2] || b > n.p[3]) return false;
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
     t = tt;
     ua = a;
     vb = b;
     return true;
 }
+__device__ __forceinline__ bool hit_rect(const SceneNode& n, const Ray& r, double t_min, double t_max, double& t,
+                                         double& ua, double& vb) {
+    const int ka = n.kind == RT_NODE_XY_RECT ? 2 : (n.kind == RT_NODE_XZ_RECT ? 1 : 0);
+    const int aa = n.kind == RT_NODE_YZ_RECT ? 1 : 0;
+    const int ba = n.kind == RT_NODE_XY_RECT ? 1 : 2;
+    return hit_rect_raw(ka, aa, ba, n.p[0], n.p[1], n.p[2], n.p[3], n.p[4], r, t_min, t_max, t, ua, vb);
+}
 
+// box::hit (B2/box.h:41-43 = hittable_list::hit over the six sides of B2/box.h:31-38) for a box whose sides are
+// exactly those the reference's constructor derives from (p0, p1) and whose side nodes are numbered consecutively
+// (checked at upload): the six rectangle tests in the reference's order with the closest-so-far value, from the two
+// corners alone.  Returns the index 0..5 of the winning side, or -1.
+__device__ __forceinline__ int hit_box6(const double* p, const Ray& r, double t_min, double& t_max) {
+    const double x0 = p[0], y0 = p[1], z0 = p[2], x1 = p[3], y1 = p[4], z1 = p[5];
+    int side = -1;
+    double t, ua, vb;
+    if (hit_rect_raw(2, 0, 1, x0, x1, y0, y1, z1, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 0; }
+    if (hit_rect_raw(2, 0, 1, x0, x1, y0, y1, z0, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 1; }
+    if (hit_rect_raw(1, 0, 2, x0, x1, z0, z1, y1, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 2; }
+    if (hit_rect_raw(1, 0, 2, x0, x1, z0, z1, y0, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 3; }
+    if (hit_rect_raw(0, 1, 2, y0, y1, z0, z1, x1, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 4; }
+    if (hit_rect_raw(0, 1, 2, y0, y1, z0, z1, x0, r, t_min, t_max, t, ua, vb)) { t_max = t; side = 5; }
+    return side;
+}
+
+template <int F>
 __device__ __forceinline__ bool prim_hit(const SceneDev& S, const SceneNode& n, const Ray& r, double a, double tm,
                                          double t_min, double t_max, double& t) {
-    double ua, vb;
-    switch (n.kind) {
-    case RT_NODE_SPHERE: return hit_sphere(d3{n.p[0], n.p[1], n.p[2]}, n.p[3], r, a, t_min, t_max, t);
-    case RT_NODE_MOVING_SPHERE: return hit_sphere(moving_center(S, n, tm), S.extra[n.c + 2], r, a, t_min, t_max, t);
-    case RT_NODE_XY_RECT:
-    case RT_NODE_XZ_RECT:
-    case RT_NODE_YZ_RECT: return hit_rect(n, r, t_min, t_max, t, ua, vb);
-    default: return false;
+    if (n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_MOVING_SPHERE) {  // one copy of the quadratic for both
+        d3 center{n.p[0], n.p[1], n.p[2]};
+        double radius = n.p[3];
+        if constexpr ((F & F_MOVING) != 0) {
+            if (n.kind == RT_NODE_MOVING_SPHERE) {
+                center = moving_center(S, n, tm);
+                radius = S.extra[n.c + 2];
+            }
+        }
+        return hit_sphere(center, radius, r, a, t_min, t_max, t);
     }
+    if constexpr ((F & F_RECT) != 0) {
+        if (n.kind == RT_NODE_XY_RECT || n.kind == RT_NODE_XZ_RECT || n.kind == RT_NODE_YZ_RECT) {
+            double ua, vb;
+            return hit_rect(n, r, t_min, t_max, t, ua, vb);
+        }
+    }
+    return false;
 }
 
 // aabb::hit (B2/aabb.h:34-47) with the per-axis reciprocal computed once per ray (same value)
@@ -143,6 +222,7 @@ __device__ __forceinline__ bool hit_aabb(const double* p, const Ray& r, d3 inv, 
 // boundary->hit(r, t_min, t_max, rec) as constant_medium::hit calls it; only rec.t is used there.
 // Supported boundaries: a sphere, moving sphere, rectangle, a list/box of those, under up to
 // XF_DEPTH_CAP translate / rotate_y levels (checked at upload).
+template <int F>
 __device__ __forceinline__ bool boundary_hit(const SceneDev& S, int node, Ray r, double tm, double t_min, double t_max,
                                              double& t_out) {
     SceneNode n = S.nodes[node];
@@ -151,13 +231,13 @@ __device__ __forceinline__ bool boundary_hit(const SceneDev& S, int node, Ray r,
         n = S.nodes[n.a];
     }
     const double a = len2(r.d);
-    if (n.kind == RT_NODE_LIST || n.kind == RT_NODE_BOX) {
+    if (n.kind == RT_NODE_LIST || n.kind == RT_NODE_BOX || n.kind == DEV_NODE_BOX6) {
         bool any = false;
         double best = t_max;
         for (int i = 0; i < n.b; ++i) {
             const SceneNode c = S.nodes[S.children[n.a + i]];
             double t;
-            if (prim_hit(S, c, r, a, tm, t_min, best, t)) {
+            if (prim_hit<F>(S, c, r, a, tm, t_min, best, t)) {
                 best = t;
                 any = true;
             }
@@ -165,7 +245,7 @@ __device__ __forceinline__ bool boundary_hit(const SceneDev& S, int node, Ray r,
         t_out = best;
         return any;
     }
-    return prim_hit(S, n, r, a, tm, t_min, t_max, t_out);
+    return prim_hit<F>(S, n, r, a, tm, t_min, t_max, t_out);
 }
 
 struct Hit {
@@ -178,7 +258,44 @@ struct RngCtx {
     uint32_t pixel, sample, site, k0, k1;
 };
 
+// constant_medium::hit (B2/constant_medium.h:30-66) for medium node `e`; updates h when the ray scatters inside.
+template <int F>
+__device__ __forceinline__ void medium_hit(const SceneDev& S, const SceneNode& n, int e, const Ray& cur, int cur_xf,
+                                           double tm, const RngCtx& g, Hit& h) {
+    double t1, t2;
+    const SceneNode bn = S.nodes[n.b];
+    if (bn.kind == RT_NODE_SPHERE) {  // both boundary searches from one evaluation of the quadratic
+        const SphereRoots sr = sphere_roots(d3{bn.p[0], bn.p[1], bn.p[2]}, bn.p[3], cur, len2(cur.d));
+        if (!pick_root(sr, -__builtin_inf(), __builtin_inf(), t1)) return;
+        if (!pick_root(sr, t1 + 0.0001, __builtin_inf(), t2)) return;
+    } else {
+        if (!boundary_hit<F>(S, n.b, cur, tm, -__builtin_inf(), __builtin_inf(), t1)) return;
+        if (!boundary_hit<F>(S, n.b, cur, tm, t1 + 0.0001, __builtin_inf(), t2)) return;
+    }
+    if (t1 < T_MIN) t1 = T_MIN;
+    if (t2 > h.t) t2 = h.t;
+    if (t1 >= t2) return;
+    if (t1 < 0) t1 = 0;
+    const double ray_length = sqrt(len2(cur.d));
+    const double distance_inside_boundary = (t2 - t1) * ray_length;
+    const u32x4 wd = philox4x32_10(g.pixel, g.sample, g.site, TRY_MEDIUM + (uint32_t)e, g.k0, g.k1);
+    const double hit_distance = n.p[0] * log(u01(wd.x));
+    if (hit_distance > distance_inside_boundary) return;
+    h.t = t1 + hit_distance / ray_length;
+    h.node = e;
+    h.xf = cur_xf;
+}
+
 // world.hit(r, 0.001, infinity, rec) for one ray per lane.  All 64 lanes must call it.
+// One entry per lane and trip, whatever its kind: letting lanes with a leaf wait for the others to reach
+// one (separate box and leaf phases) was measured 1.2-1.6x slower -- the loop is bound by the latency of
+// the dependent stack and node loads, not by the instructions of the cases.  (Testing a box's six sides in one
+// trip instead of walking them through the stack was also measured slower, for the same reason.)
+#ifdef RT_SCENE_PROBE
+// debug build: per-lane counters of the traversal loop, summed and printed by the render kernel
+static __device__ unsigned long long g_probe_total[16];  // [kind] entries, [12] trips, [13] lane-trips, [14] traces
+#endif
+template <int F>
 __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, uint32_t* stack, int lane,
                                      const RngCtx& g) {
     Hit h{__builtin_inf(), -1, -1};
@@ -188,70 +305,73 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
     double a = len2(cur.d);
     int sp = 0;
     if (on) stack[(sp++) * 64 + lane] = (uint32_t)S.root;
+#ifdef RT_SCENE_PROBE
+    if (lane == 0) atomicAdd(&g_probe_total[14], 1ull);
+#endif
 
     while (ballot(sp > 0) != 0ull) {
+#ifdef RT_SCENE_PROBE
+        if (lane == 0) {
+            atomicAdd(&g_probe_total[12], 1ull);
+            atomicAdd(&g_probe_total[13], (unsigned long long)__popcll(ballot(sp > 0)));
+        }
+#endif
         if (sp > 0) {
             const uint32_t entry = stack[(--sp) * 64 + lane];
             const int e = (int)(entry & 0xFFFFu);
             const uint32_t tag = entry >> 16;
-            if (tag == END_XF) {
-                cur_xf = S.parent_xf[e];
-                cur = ray_in(S, cur_xf, w);
-                inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
-                a = len2(cur.d);
-                continue;
+            if constexpr ((F & F_XF) != 0) {
+                if (tag >= END_XF_TRANSLATE) {  // leave instance node e: back to the ray of the level above
+                    cur_xf = S.parent_xf[e];
+                    cur = ray_in<F>(S, cur_xf, w);
+                    if (tag == END_XF) {  // a translation leaves the direction, hence inv and a, as they were
+                        inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
+                        a = len2(cur.d);
+                    }
+                    continue;
+                }
             }
             const SceneNode n = S.nodes[e];
-            switch (n.kind) {
-            case RT_NODE_BVH:
+            const int kind = n.kind;
+#ifdef RT_SCENE_PROBE
+            atomicAdd(&g_probe_total[kind < 12 ? kind : 0], 1ull);
+#endif
+            if (kind == RT_NODE_BVH) {
                 if (hit_aabb(n.p, cur, inv, T_MIN, h.t)) {
                     stack[(sp++) * 64 + lane] = (uint32_t)n.b;
                     stack[(sp++) * 64 + lane] = (uint32_t)n.a;
                 }
-                break;
-            case RT_NODE_LIST:
-            case RT_NODE_BOX:  // visit child `tag` next; the list stays on the stack until its last child
+            } else if (kind == RT_NODE_LIST || kind == RT_NODE_BOX) {
+                // visit child `tag` next; the list stays on the stack until its last child
                 if ((int)tag < n.b) {
                     if ((int)tag + 1 < n.b) stack[(sp++) * 64 + lane] = (uint32_t)e | ((tag + 1u) << 16);
                     stack[(sp++) * 64 + lane] = (uint32_t)S.children[n.a + (int)tag];
                 }
-                break;
-            case RT_NODE_TRANSLATE:
-            case RT_NODE_ROTATE_Y:
-                stack[(sp++) * 64 + lane] = (uint32_t)e | (END_XF << 16);
+            } else if ((F & F_XF) != 0 && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y)) {
+                const bool rotates = kind == RT_NODE_ROTATE_Y;
+                stack[(sp++) * 64 + lane] = (uint32_t)e | ((rotates ? END_XF : END_XF_TRANSLATE) << 16);
                 stack[(sp++) * 64 + lane] = (uint32_t)n.a;
                 cur = xf_apply(n, cur);
                 cur_xf = e;
-                inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
-                a = len2(cur.d);
-                break;
-            case RT_NODE_MEDIUM: {  // B2/constant_medium.h:35-52
-                double t1, t2;
-                if (!boundary_hit(S, n.b, cur, tm, -__builtin_inf(), __builtin_inf(), t1)) break;
-                if (!boundary_hit(S, n.b, cur, tm, t1 + 0.0001, __builtin_inf(), t2)) break;
-                if (t1 < T_MIN) t1 = T_MIN;
-                if (t2 > h.t) t2 = h.t;
-                if (t1 >= t2) break;
-                if (t1 < 0) t1 = 0;
-                const double ray_length = sqrt(len2(cur.d));
-                const double distance_inside_boundary = (t2 - t1) * ray_length;
-                const u32x4 wd = philox4x32_10(g.pixel, g.sample, g.site, TRY_MEDIUM + (uint32_t)e, g.k0, g.k1);
-                const double hit_distance = n.p[0] * log(u01(wd.x));
-                if (hit_distance > distance_inside_boundary) break;
-                h.t = t1 + hit_distance / ray_length;
-                h.node = e;
-                h.xf = cur_xf;
-                break;
-            }
-            default: {  // primitives
+                if (rotates) {
+                    inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
+                    a = len2(cur.d);
+                }
+            } else if ((F & F_RECT) != 0 && kind == DEV_NODE_BOX6) {
+                const int side = hit_box6(n.p, cur, T_MIN, h.t);
+                if (side >= 0) {
+                    h.node = n.c + side;
+                    h.xf = cur_xf;
+                }
+            } else if ((F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM) {
+                medium_hit<F>(S, n, e, cur, cur_xf, tm, g, h);
+            } else {
                 double t;
-                if (prim_hit(S, n, cur, a, tm, T_MIN, h.t, t)) {
+                if (prim_hit<F>(S, n, cur, a, tm, T_MIN, h.t, t)) {
                     h.t = t;
                     h.node = e;
                     h.xf = cur_xf;
                 }
-                break;
-            }
             }
         }
     }
@@ -272,19 +392,20 @@ __device__ __forceinline__ void set_face_normal(Surface& s, const Ray& r, d3 out
     s.normal = s.front_face ? outward_normal : -outward_normal;
 }
 
+template <int F>
 __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h, Ray w, double tm) {
     Surface s;
     s.u = s.v = 0.0;  // moving_sphere and constant_medium leave u,v untouched in the reference
     s.sphere_uv = false;
     s.outward = d3{0, 0, 0};
     const SceneNode n = S.nodes[h.node];
-    const Ray local = ray_in(S, h.xf, w);
+    const Ray local = ray_in<F>(S, h.xf, w);
     s.p = local.o + h.t * local.d;
     s.mat = n.a;
     switch (n.kind) {
     case RT_NODE_SPHERE:
     case RT_NODE_MOVING_SPHERE: {
-        const bool moving = n.kind == RT_NODE_MOVING_SPHERE;
+        const bool moving = (F & F_MOVING) != 0 && n.kind == RT_NODE_MOVING_SPHERE;
         const d3 center = moving ? moving_center(S, n, tm) : d3{n.p[0], n.p[1], n.p[2]};
         const double radius = moving ? S.extra[n.c + 2] : n.p[3];
         const d3 outward_normal = div_by(s.p - center, radius);
@@ -296,6 +417,7 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
     case RT_NODE_XY_RECT:
     case RT_NODE_XZ_RECT:
     case RT_NODE_YZ_RECT: {  // B2/aarect.h:36-43
+        if constexpr (!(F & F_RECT)) break;
         double t, ua, vb;
         hit_rect(n, local, h.t, h.t, t, ua, vb);  // same arithmetic as the accepted test: recovers a, b
         s.u = (ua - n.p[0]) / (n.p[1] - n.p[0]);
@@ -310,9 +432,10 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
         break;
     }
     // back out through the enclosing instances, innermost first (B2/hittable.h:48-49, 127-137)
+    if constexpr ((F & F_XF) != 0)
     for (int x = h.xf, lvl = 0; x >= 0 && lvl < XF_DEPTH_CAP; x = S.parent_xf[x], ++lvl) {
         const SceneNode xn = S.nodes[x];
-        const Ray child_ray = ray_in(S, x, w);
+        const Ray child_ray = ray_in<F>(S, x, w);
         if (xn.kind == RT_NODE_TRANSLATE) {
             s.p = s.p + d3{xn.p[0], xn.p[1], xn.p[2]};
             set_face_normal(s, child_ray, s.normal);
@@ -369,20 +492,22 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {  // B
 }
 
 // texture::value (B2/texture.h).  Checker textures are followed iteratively (at most 4 levels).
+template <int F>
 __device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& s) {
     for (int level = 0; level < 4; ++level) {
         const TextureDev t = S.textures[ti];
-        if (t.kind == RT_TEX_CHECKER) {
+        if ((F & F_CHECKER) != 0 && t.kind == RT_TEX_CHECKER) {
             const double sines = sin(10 * s.p.x) * sin(10 * s.p.y) * sin(10 * s.p.z);
             ti = sines < 0 ? t.b : t.a;
             continue;
         }
         if (t.kind == RT_TEX_SOLID) return d3{t.p[0], t.p[1], t.p[2]};
-        if (t.kind == RT_TEX_NOISE) {
+        if ((F & F_NOISE) != 0 && t.kind == RT_TEX_NOISE) {
             const double f = 1 + sin(t.p[0] * s.p.z + 10 * perlin_turb(S.perlins[t.a], s.p));
             return f * (0.5 * d3{1, 1, 1});
         }
         // RT_TEX_IMAGE, B2/texture.h:85-104
+        if constexpr (!(F & F_IMAGE)) return d3{0, 1, 1};
         if (t.a < 0 || S.images[t.a].rgb == nullptr) return d3{0, 1, 1};
         if (s.sphere_uv) {  // get_sphere_uv, B2/sphere.h:33-37
             const double pi = 3.14159265358979323846;
@@ -422,7 +547,11 @@ __device__ __forceinline__ Ray primary_ray(const CameraDev& C, int W, int H, uin
 }  // namespace
 
 // ---------------------------------------------------------------- render kernel
-__global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
+#ifndef RT_SCENE_MIN_WAVES
+#define RT_SCENE_MIN_WAVES 3
+#endif
+template <int F, int MIN_WAVES>
+__global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRenderArgs A) {
     __shared__ uint32_t s_stack[4][STACK_CAP * 64];
     const int lane = threadIdx.x & 63;
     uint32_t* stack = s_stack[threadIdx.x >> 6];
@@ -453,7 +582,7 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
         }
         const bool on = active;
         const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
-        const Hit h = trace(S, r, tm, on, stack, lane, g);
+        const Hit h = trace<F>(S, r, tm, on, stack, lane, g);
 
         if (on) {
             ++n_rays;
@@ -469,7 +598,7 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
                 }
                 done = true;
             } else {
-                Surface s = make_surface(S, h, r, tm);
+                Surface s = make_surface<F>(S, h, r, tm);
                 const MaterialDev m = S.materials[s.mat];
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
@@ -479,7 +608,7 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
                     nd = s.normal + unit_vector(rs);
                     const double eps = 1e-8;
                     if ((fabs(nd.x) < eps) && (fabs(nd.y) < eps) && (fabs(nd.z) < eps)) nd = s.normal;
-                    attenuation = texture_value(S, m.tex, s);
+                    attenuation = texture_value<F>(S, m.tex, s);
                 } else if (m.kind == RT_MAT_METAL) {  // B2/material.h:46-53
                     const d3 reflected = reflect(unit_vector(r.d), s.normal);
                     nd = reflected + m.param * rs;
@@ -496,11 +625,11 @@ __global__ void __launch_bounds__(256) k_render_scene(const SceneRenderArgs A) {
                         do_reflect = reflectance(cos_theta, refraction_ratio) > u01(w.x);
                     }
                     nd = do_reflect ? reflect(unit_direction, s.normal) : refract(unit_direction, s.normal, refraction_ratio);
-                } else if (m.kind == RT_MAT_ISOTROPIC) {  // B2/material.h:121-127
+                } else if ((F & F_MEDIUM) != 0 && m.kind == RT_MAT_ISOTROPIC) {  // B2/material.h:121-127
                     nd = rs;
-                    attenuation = texture_value(S, m.tex, s);
+                    attenuation = texture_value<F>(S, m.tex, s);
                 } else {  // diffuse_light: emits, does not scatter (B2/material.h:102-110)
-                    L_end = texture_value(S, m.tex, s);
+                    L_end = texture_value<F>(S, m.tex, s);
                     done = true;
                 }
                 if (!done) {
@@ -555,12 +684,40 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
     const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
     const Ray r{origin + offset, llc + s * hor + t * ver - origin - offset};
     const RngCtx g{pc, 0u, 1u, 0u, 0u};
-    const Hit h = trace(A.scene, r, C.time0, on, stack, lane, g);
+    const Hit h = trace<F_ALL>(A.scene, r, C.time0, on, stack, lane, g);
     if (on) A.ids[pixel] = h.node < 0 ? -1 : A.scene.top_of[h.node];
 }
 
+// Compiled variants, most specialised first; a world runs the first one that covers its features.
+// MIN_WAVES is the occupancy the register allocator is held to (measured best per variant).
+#ifndef RT_SCENE_WAVES_A
+#define RT_SCENE_WAVES_A 3
+#endif
+#ifndef RT_SCENE_WAVES_B
+#define RT_SCENE_WAVES_B 3
+#endif
+constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
+constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
+constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE;  // textured spheres and lights
+typedef void (*scene_kernel_t)(const SceneRenderArgs);
+struct SceneVariant {
+    int features;
+    scene_kernel_t kernel;
+};
+static const SceneVariant g_variants[] = {
+    {V_A, k_render_scene<V_A, RT_SCENE_WAVES_A>},
+    {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
+    {V_C, k_render_scene<V_C, 2>},
+    {F_ALL, k_render_scene<F_ALL, RT_SCENE_MIN_WAVES>},
+};
+static const SceneVariant& variant_for(int features) {
+    for (const SceneVariant& v : g_variants)
+        if ((features & ~v.features) == 0) return v;
+    return g_variants[sizeof(g_variants) / sizeof(g_variants[0]) - 1];
+}
+
 hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_render_scene, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(variant_for(args.scene.features).kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -570,9 +727,41 @@ hipError_t launch_first_hit_scene(const SceneFirstHitArgs& args, hipStream_t str
     return hipGetLastError();
 }
 
-int render_scene_blocks_per_cu() {
+#ifdef RT_SCENE_PROBE
+void scene_probe_dump() {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_total), sizeof(h)) != hipSuccess) return;
+    static const char* names[] = {"other", "sphere", "moving", "xy", "xz", "yz", "box", "list", "bvh", "translate", "rotate", "medium"};
+    std::fprintf(stderr, "scene probe: wave-traces %llu  trips %llu (%.1f per trace)  lane fill %.3f\n", h[14], h[12],
+                 (double)h[12] / (double)(h[14] ? h[14] : 1), (double)h[13] / (64.0 * (double)(h[12] ? h[12] : 1)));
+    for (int k = 0; k < 12; ++k)
+        if (h[k]) std::fprintf(stderr, "  entries %-9s %12llu  (%.2f per lane-trip)\n", names[k], h[k], (double)h[k] / (double)h[13]);
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_total), z, sizeof(z));
+}
+#endif
+
+int scene_feature_bit_for_node(int kind) {
+    switch (kind) {
+    case RT_NODE_MOVING_SPHERE: return F_MOVING;
+    case RT_NODE_XY_RECT:
+    case RT_NODE_XZ_RECT:
+    case RT_NODE_YZ_RECT:
+    case RT_NODE_BOX: return F_RECT;
+    case RT_NODE_TRANSLATE:
+    case RT_NODE_ROTATE_Y: return F_XF;
+    case RT_NODE_MEDIUM: return F_MEDIUM;
+    default: return 0;
+    }
+}
+int scene_feature_bit_for_texture(int kind) {
+    return kind == RT_TEX_CHECKER ? F_CHECKER : kind == RT_TEX_NOISE ? F_NOISE : kind == RT_TEX_IMAGE ? F_IMAGE : 0;
+}
+int scene_feature_bit_for_material(int kind) { return kind == RT_MAT_ISOTROPIC ? F_MEDIUM : 0; }
+
+int render_scene_blocks_per_cu(int features) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_scene, 256, 0) != hipSuccess || n < 1) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, variant_for(features).kernel, 256, 0) != hipSuccess || n < 1) n = 1;
     return n;
 }
 

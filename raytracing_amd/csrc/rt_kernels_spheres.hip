@@ -30,6 +30,27 @@
 
 namespace rtd {
 
+// Section clock of the debug build (-DRT_TAIL_PROBE): elapsed cycles of a wave per kernel section.
+// Empty, and compiled away, otherwise.
+#ifdef RT_TAIL_PROBE
+struct ProbeClock {
+    uint64_t sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t last = 0;
+    __device__ __forceinline__ void start() { last = clock64(); }
+    __device__ __forceinline__ void mark(int k) {
+        const uint64_t now = clock64();
+        sec[k] += now - last;
+        last = now;
+    }
+};
+#else
+struct ProbeClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+enum { SEC_REFILL = 0, SEC_SCREEN_DENSE, SEC_SCREEN_SPARSE, SEC_EXACT, SEC_SHADE, SEC_PREP };
+
 // ---------------------------------------------------------------- screening pass
 //
 // For a ray o + t*d (d normalised to d^) and a sphere (c, r), real roots exist iff
@@ -154,7 +175,8 @@ __device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d
 // of the wave (wave-level loops); lanes with on == false take no part in the result.
 // `list` = this wave's CAND_CAP*64 uint16 slots in LDS.
 __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, bool on, bool exact_only,
-                                           uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count) {
+                                           uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
+                                           ProbeClock& pc) {
     const double a = len2(d);
     const double t_min = 0.001;  // B1/RayTracing.cpp:17
     Hit h{__builtin_inf(), -1};
@@ -169,6 +191,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
     const ScreenRay sr = screen_prepare(o, d, a);
     uint32_t cnt = 0;
     const uint64_t on_mask = ballot(on);
+    pc.mark(SEC_PREP);
     if (__popcll(on_mask) <= SPARSE_MAX_RAYS) {
         for (int c = 0; c < S.n_chunks; ++c) {
             const SpherePair* mine = S.screen + (size_t)c * SPARSE_CHUNK_PAIRS + (size_t)lane * 4;
@@ -208,6 +231,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
             }
             __builtin_amdgcn_wave_barrier();
         }
+        pc.mark(SEC_SCREEN_SPARSE);
     } else {
     // The screen image is immutable for the whole launch: address it through the constant
     // address space so that the wave-uniform reads become scalar loads (SGPR operands).
@@ -235,6 +259,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
             }
         }
     }
+    pc.mark(SEC_SCREEN_DENSE);
     }
 
     const bool overflow = cnt > (uint32_t)CAND_CAP;
@@ -248,6 +273,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
             for (int j = 0; j < S.n; ++j) exact_one(S, j, o, d, a, t_min, h);
         }
     }
+    pc.mark(SEC_EXACT);
     return h;
 }
 
@@ -279,6 +305,8 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     uint64_t pr_tq = 0, pr_iters = 0, pr_iters_q = 0, pr_lanes_q = 0, pr_lanes = 0;
 #endif
 
+    ProbeClock pc;
+    pc.start();
     for (;;) {
         // ---- refill: finish items, take new ones, start the next sample
         if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
@@ -294,6 +322,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
         }
         // ---- closest hit (all lanes together)
         const bool on = active;
+        pc.mark(SEC_REFILL);
 #ifdef RT_TAIL_PROBE
         {
             const uint64_t na = (uint64_t)__popcll(ballot(on));
@@ -306,7 +335,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             }
         }
 #endif
-        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, rows, lane, n_overflow);
+        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, rows, lane, n_overflow, pc);
 
         // ---- shade
         if (on) {
@@ -373,11 +402,13 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
                 ++w.s_cur;
             }
         }
+        pc.mark(SEC_SHADE);
     }
 
 #ifdef RT_TAIL_PROBE
     if (lane == 0 && A.probe) {
-        uint64_t* w = A.probe + 8ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        uint64_t* w = A.probe + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        for (int k = 0; k < 8; ++k) w[8 + k] = pc.sec[k];
         w[0] = pr_t0;
         w[1] = pr_tq;
         w[2] = wall_clock64();
@@ -431,7 +462,8 @@ __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A)
     const d3 o = origin + offset;
     const d3 d = llc + s * hor + t * ver - origin - offset;
     uint32_t ovf = 0;
-    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, rows, lane, ovf);
+    ProbeClock clk;
+    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, rows, lane, ovf, clk);
     if (on) A.ids[pixel] = h.id;
 }
 

@@ -63,6 +63,48 @@ def test_scene_first_hit_ids(ctx, kat_b2, name):
     assert np.array_equal(ids, np.load(gold(f"b2_{name}_firsthit.npz"))["ids"].astype(np.int32))
 
 
+@pytest.mark.parametrize("name", ["bouncing", "cornell_box", "cornell_smoke", "two_perlin", "final"])
+def test_specialised_and_general_kernel_variants_agree(ctx, kat_b2, name, monkeypatch):
+    """A world runs the kernel variant compiled for the features it uses; the general variant gives the same bits."""
+    k = kat_b2[name]
+    scene = load_b2(name)
+    cam = camera_b2(k, lib.camera)
+    p = abi.render_params(64, 48, 4, 50, seed=12)
+    ctx.upload(scene)
+    a, sa = ctx.render(cam, p)
+    monkeypatch.setenv("RT_SCENE_VARIANT", "all")
+    ctx.upload(scene)
+    b, sb = ctx.render(cam, p)
+    monkeypatch.delenv("RT_SCENE_VARIANT")
+    ctx.upload(scene)
+    assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+
+
+@pytest.mark.parametrize("change", ["shrunk_side", "swapped_sides"])
+def test_boxes_unlike_the_reference_constructor_walk_their_sides(ctx, kat_b2, change):
+    """Boxes whose six sides are the ones box::box derives from the corners are tested from the corners; any other
+    box is an ordinary list of its sides.  Both must match the oracle, which always walks the list."""
+    import copy
+    k = kat_b2["cornell_box"]
+    scene = copy.deepcopy(load_b2("cornell_box"))
+    boxes = np.flatnonzero(scene.nodes["kind"] == abi.RT_NODE_BOX)
+    assert len(boxes) == 2
+    b = scene.nodes[boxes[0]]
+    kids = scene.children[b["child0"]: b["child0"] + 6].copy()
+    if change == "shrunk_side":
+        scene.nodes["p"][kids[2]][1] -= 20.0   # top face no longer spans the box
+    else:
+        scene.children[b["child0"]], scene.children[b["child0"] + 1] = kids[1], kids[0]
+    cam = camera_b2(k, lib.camera)
+    ctx.upload(scene)
+    p = abi.render_params(60, 60, 4, 50, seed=21)
+    got, st = ctx.render(cam, p)
+    want, ost = oracle_sums(scene, cam, p)
+    assert st["rays"] == ost["rays"]
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.first_hit(cam, 90, 90), ob.first_hit(scene, cam, 90, 90))
+
+
 def test_sphere_list_scene_through_graph_kernels(ctx, scene_c2):
     """The two kernel families agree bit for bit on a scene both can render."""
     cam = lib.camera(*CAM_C2)

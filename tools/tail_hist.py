@@ -29,7 +29,7 @@ for rep in range(2):
     ctx.synchronize()
     st = ctx.take_stats()
 print("kernel ms", st["kernel_ms"])
-p = np.fromfile(OUT, dtype=np.uint64).reshape(-1, 8)
+p = np.fromfile(OUT, dtype=np.uint64).reshape(-1, 16)
 p = p[p[:, 7] == 1].astype(np.float64)
 t0 = p[:, 0].min()
 tick = 1e-5  # ms per tick at 100 MHz
@@ -44,4 +44,8 @@ print(f"wave-iterations after dry / total: {p[:,4].sum() / p[:,3].sum():.4f}")
 edges = np.linspace(np.median(tq[p[:, 1] > 0]), tx.max(), 13)
 alive = [(tx > e).sum() for e in edges]
 print("waves alive after dry:", " ".join(f"{e - edges[0]:.2f}ms:{a}" for e, a in zip(edges, alive)))
+sec = p[:, 8:14].sum(axis=0)
+names = ["refill+camera", "screen dense", "screen sparse", "exact", "shade", "screen prep"]
+print("wave time by section: " + "  ".join(f"{n} {100 * v / sec.sum():.1f}%" for n, v in zip(names, sec)))
+print(f"cycles per wave trip: {sec.sum() / p[:, 3].sum():.0f} (clock64 ticks), sections: " + " ".join(f"{v / p[:, 3].sum():.0f}" for v in sec))
 ctx.close()
