@@ -553,8 +553,20 @@ __device__ __forceinline__ Ray primary_ray(const CameraDev& C, int W, int H, uin
 template <int F, int MIN_WAVES>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRenderArgs A) {
     __shared__ uint32_t s_stack[4][STACK_CAP * 64];
+    // The camera (21 doubles) is needed once per sample; read from the kernel arguments it would sit in 42 scalar
+    // registers for the whole kernel and push hot values out.  One copy per wave in LDS, read back where it is used.
+    __shared__ CameraDev s_cam[4];
     const int lane = threadIdx.x & 63;
     uint32_t* stack = s_stack[threadIdx.x >> 6];
+    {
+        const double* src = (const double*)&A.cam;
+        double* dst = (double*)&s_cam[threadIdx.x >> 6];
+        if (lane < (int)(sizeof(CameraDev) / sizeof(double))) dst[lane] = src[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const CameraDev& cam = s_cam[threadIdx.x >> 6];
     const SceneDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
@@ -573,7 +585,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     for (;;) {
         if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
         if (!active && w.has_item) {
-            r = primary_ray(A.cam, A.width, A.height, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, tm);
+            r = primary_ray(cam, A.width, A.height, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, tm);
             T = d3{1, 1, 1};
             depth_left = A.max_depth;
             bounce = 0;

@@ -287,6 +287,18 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
     uint32_t* rows = s_rows[threadIdx.x >> 6];
+    // The camera (21 doubles) is needed once per sample; read from the kernel arguments it would sit in 42 scalar
+    // registers for the whole kernel.  One copy per wave in LDS, read back where it is used.
+    __shared__ CameraDev s_cam[4];
+    {
+        const double* src = (const double*)&A.cam;
+        double* dst = (double*)&s_cam[threadIdx.x >> 6];
+        if (lane < (int)(sizeof(CameraDev) / sizeof(double))) dst[lane] = src[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const CameraDev& cam = s_cam[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
@@ -313,7 +325,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
         if (!active && w.has_item) {
             const int i = (int)(w.pixel % (uint32_t)A.width);
             const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
-            camera_ray(A.cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, o, d);
+            camera_ray(cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, o, d);
             T = d3{1, 1, 1};
             depth_left = A.max_depth;
             bounce = 0;

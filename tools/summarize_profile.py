@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condenses the rocprofv3 output of tools/profile_bench.sh into profiles/<tag>_*.{md,json}.
 
-    python tools/summarize_profile.py r01
+    python tools/summarize_profile.py r01                                   # bench.py, k_render_spheres
+    python tools/summarize_profile.py r01_final k_render_scene scene_final  # tools/profile_scene.sh output
 
 Reads gpurun_out/prof_<tag>/trace/bench_kernel_stats.csv (kernel-trace --stats) and the
 counter_collection.csv of each counter pass; writes a summary the repository keeps.
@@ -18,14 +19,23 @@ KERNEL = "k_render_spheres"
 
 
 def main():
+    global KERNEL
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    if len(sys.argv) > 2:
+        KERNEL = sys.argv[2]
+    out_name = sys.argv[3] if len(sys.argv) > 3 else "bench_c2"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
 
     stats_rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
-    with open(os.path.join(src, "trace_bench.json")) as fp:
-        bench = json.loads(fp.read().strip().splitlines()[-1])
+    bench, bench_text = None, ""
+    if os.path.exists(os.path.join(src, "trace_bench.json")):
+        with open(os.path.join(src, "trace_bench.json")) as fp:
+            bench = json.loads(fp.read().strip().splitlines()[-1])
+    elif os.path.exists(os.path.join(src, "trace_bench.txt")):
+        with open(os.path.join(src, "trace_bench.txt")) as fp:
+            bench_text = "".join(l for l in fp if "amdgpu.ids" not in l).strip()
 
     counters = collections.OrderedDict()
     launches = {}
@@ -63,30 +73,46 @@ def main():
         derived["hbm_write_MB_per_launch"] = c["WRITE_SIZE"] * 1024 / 1e6
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         derived["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        # share of cycles in which a SIMD issues a VALU instruction, pricing one at the measured ~4.1 cycles
+        derived["valu_busy_estimate"] = min(1.0, derived["valu_wave_instr_per_cycle_per_simd"] * 4.1)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
+        derived["l1_requests_served_without_l2"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
 
-    summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (under rocprofv3)",
-               "kernel_stats": stats_rows, "bench_line_under_profiler": bench,
+    if bench is not None:
+        command = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+        title = "bench.py, One-Weekend final scene"
+        script = "tools/profile_bench.sh"
+    else:
+        command = "python3 tools/bench_scenes.py <spp> <scene>"
+        title = f"tools/bench_scenes.py ({out_name})"
+        script = "tools/profile_scene.sh"
+    summary = {"tag": tag, "command": command + " (under rocprofv3)",
+               "kernel_stats": stats_rows, "bench_line_under_profiler": bench if bench is not None else bench_text,
                "counters_per_launch": counters, "derived": derived}
-    with open(os.path.join(out_dir, f"{tag}_bench_c2.json"), "w") as fp:
+    with open(os.path.join(out_dir, f"{tag}_{out_name}.json"), "w") as fp:
         json.dump(summary, fp, indent=1)
 
-    lines = [f"# rocprofv3 summary `{tag}`: bench.py, One-Weekend final scene, 1 x MI355X", "",
-             "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
-             "(counter passes: one `rocprofv3 --pmc ...` run each, 1 step; see tools/profile_bench.sh).", "",
+    lines = [f"# rocprofv3 summary `{tag}`: {title}, 1 x MI355X", "",
+             f"Command: `rocprofv3 --kernel-trace --stats -- {command}`",
+             f"(counter passes: one `rocprofv3 --pmc ...` run each; see {script}).", "",
              "## Kernel trace (--stats)", "", "| kernel | calls | average ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in stats_rows:
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
                      f"{float(r['MinNs']) / 1e6:.3f} | {float(r['MaxNs']) / 1e6:.3f} | {r['Percentage']} |")
-    lines += ["", f"bench.py's own event-timed average for the same kernel: {bench['roofline']['kernel_ms']:.3f} ms "
-                  f"(value {bench['value']:.1f} Msamples/s, roofline fraction {bench['roofline']['frac']:.3f}).", "",
-              "## Counters, per launch of `k_render_spheres`", "", "| counter | value |", "|---|---|"]
+    if bench is not None:
+        lines += ["", f"bench.py's own event-timed average for the same kernel: {bench['roofline']['kernel_ms']:.3f} ms "
+                      f"(value {bench['value']:.1f} Msamples/s, roofline fraction {bench['roofline']['frac']:.3f})."]
+    else:
+        lines += ["", "Output of the profiled command (event-timed kernel time of the library):", "", "```", bench_text, "```"]
+    lines += ["", f"## Counters, per launch of `{KERNEL}`", "", "| counter | value |", "|---|---|"]
     for n, v in counters.items():
         lines.append(f"| {n} | {v:.6g} |")
     lines += ["", "## Derived", "", "| quantity | value |", "|---|---|"]
     for n, v in derived.items():
         lines.append(f"| {n} | {v:.4g} |")
     lines.append("")
-    with open(os.path.join(out_dir, f"{tag}_bench_c2.md"), "w") as fp:
+    with open(os.path.join(out_dir, f"{tag}_{out_name}.md"), "w") as fp:
         fp.write("\n".join(lines))
     print("\n".join(lines))
 
