@@ -357,9 +357,19 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             const uint32_t site = 1u + bounce;
             bool done = false;
             d3 L_end{0, 0, 0};
-            if (h.id < 0) {
+            const bool hit = h.id >= 0;
+            SphereExact e{0, 0, 0, 1};
+            MaterialDev m{RT_MAT_LAMBERTIAN, -1, 0, 0, 0, 0};
+            if (hit) {
+                e = S.exact[h.id];
+                m = S.materials[S.material_of[h.id]];
+            }
+            // unit_vector(r.direction()) is wanted by the sky, by metal and by dielectric: one copy of the square
+            // root and division for all of them instead of one per divergent branch
+            d3 unit_direction{0, 0, 0};
+            if (!hit || m.kind != RT_MAT_LAMBERTIAN) unit_direction = unit_vector(d);
+            if (!hit) {
                 if (S.sky_mode == RT_SKY_GRADIENT) {  // B1/RayTracing.cpp:28-30
-                    const d3 unit_direction = unit_vector(d);
                     const double t = 0.5 * (unit_direction.y + 1.0);
                     L_end = (1.0 - t) * d3{1.0, 1.0, 1.0} + t * d3{0.5, 0.7, 1.0};
                 } else {
@@ -368,12 +378,10 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
                 done = true;
             } else {
                 // rest of sphere::hit, B1/sphere.h:43-47
-                const SphereExact e = S.exact[h.id];
                 const d3 p = o + h.t * d;
                 const d3 outward_normal = div_by(p - d3{e.cx, e.cy, e.cz}, e.radius);
                 const bool front_face = dot(d, outward_normal) < 0;
                 const d3 normal = front_face ? outward_normal : -outward_normal;
-                const MaterialDev m = S.materials[S.material_of[h.id]];
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
                 const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL;
@@ -383,19 +391,18 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
                     const double s = 1e-8;
                     if ((fabs(nd.x) < s) && (fabs(nd.y) < s) && (fabs(nd.z) < s)) nd = normal;
                 } else if (m.kind == RT_MAT_METAL) {  // B1/material.h:40-47
-                    const d3 reflected = reflect(unit_vector(d), normal);
+                    const d3 reflected = reflect(unit_direction, normal);
                     nd = reflected + m.param * rs;
                     if (!(dot(nd, normal) > 0)) done = true;  // absorbed: black
                 } else {  // dielectric, B1/material.h:58-77
                     attenuation = d3{1.0, 1.0, 1.0};
                     const double refraction_ratio = front_face ? (1.0 / m.param) : m.param;
-                    const d3 unit_direction = unit_vector(d);
                     const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
                     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
                     if (!do_reflect) {
-                        const u32x4 w = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);
-                        do_reflect = reflectance(cos_theta, refraction_ratio) > u01(w.x);
+                        const u32x4 ph = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);
+                        do_reflect = reflectance(cos_theta, refraction_ratio) > u01(ph.x);
                     }
                     nd = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
                 }
