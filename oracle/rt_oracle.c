@@ -60,11 +60,13 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* ------------------------------------------------------------------ random source
  * rand mode:   every draw is rand() / (RAND_MAX + 1.0)  (B1/rtweekend.h:24-27), consumed
  *              in the order the reference compiled with g++ consumes them.
- * philox mode: a "call" selects the block (pixel, sample, site, try); draw(slot) converts
- *              word `slot` of that block: (word >> 1) / 2^31, the same 31-bit grid.
+ * philox mode: a "call" selects the block (pixel, sample, site, block index); draw(slot)
+ *              converts word `slot` of that block: (word >> 1) / 2^31, the same 31-bit grid.
  * Sites: 0 = camera ray; 1+b = ray segment b (its medium draws and the scatter after it).
- * Tries: 0,1,2,.. = successive rejection-sampling attempts; ORC_TRY_TIME = shutter time;
- *        ORC_TRY_MEDIUM + i = the draw of the constant_medium whose node index is i.      */
+ * Block indices: 0,1,2,.. feed the rejection-sampling attempts with no word wasted (all four
+ *        words of a block are used: see get_ray and random_in_unit_sphere);
+ *        ORC_TRY_TIME = shutter time; ORC_TRY_MEDIUM + i = the draw of the constant_medium
+ *        whose node index is i.                                                          */
 #define ORC_TRY_TIME 0x80000000u
 #define ORC_TRY_MEDIUM 0x40000000u
 
@@ -87,6 +89,11 @@ static inline double rng_draw(orc_rng* g, int slot) {
     g->n_draws++;
     if (g->mode == ORC_RNG_PHILOX) return (double)(g->out[slot] >> 1) / 2147483648.0;
     return rand() / (RAND_MAX + 1.0);
+}
+/* philox mode only: the draw a saved word stands for */
+static inline double rng_draw_word(orc_rng* g, uint32_t word) {
+    g->n_draws++;
+    return (double)(word >> 1) / 2147483648.0;
 }
 /* random_double(MIN, MAX), B1/rtweekend.h:37-40 */
 static inline double rng_draw_range(orc_rng* g, int slot, double lo, double hi) {
@@ -118,12 +125,24 @@ static inline int vnear_zero(v3 a) {
 /* random_in_unit_sphere, B1/vec3.h:114-120.  vec3::random(-1,1) is
  * vec3(random_double(..), random_double(..), random_double(..)) (B1/vec3.h:52-54); g++
  * evaluates these arguments last to first, so the FIRST draw lands in z.                 */
+/* Philox: attempts 4g, 4g+1, 4g+2 take words 0,1,2 (= x,y,z) of blocks 3g, 3g+1, 3g+2 of the
+ * site; attempt 4g+3 takes the three words 3 those blocks left over (x from block 3g, y from
+ * 3g+1, z from 3g+2): four attempts per three blocks.                                      */
 static v3 random_in_unit_sphere(orc_rng* g, uint32_t site) {
+    uint32_t spare[3] = {0, 0, 0};
     for (uint32_t k = 0;; ++k) {
-        rng_call(g, site, k);
-        double z = rng_draw_range(g, 2, -1, 1);
-        double y = rng_draw_range(g, 1, -1, 1);
-        double x = rng_draw_range(g, 0, -1, 1);
+        double x, y, z;
+        if (g->mode == ORC_RNG_PHILOX && (k & 3u) == 3u) {
+            z = -1 + (1 - -1) * rng_draw_word(g, spare[2]);
+            y = -1 + (1 - -1) * rng_draw_word(g, spare[1]);
+            x = -1 + (1 - -1) * rng_draw_word(g, spare[0]);
+        } else {
+            rng_call(g, site, 3u * (k >> 2) + (k & 3u));
+            if (g->mode == ORC_RNG_PHILOX) spare[k & 3u] = g->out[3];
+            z = rng_draw_range(g, 2, -1, 1);
+            y = rng_draw_range(g, 1, -1, 1);
+            x = rng_draw_range(g, 0, -1, 1);
+        }
         v3 p = V(x, y, z);
         if (vlen2(p) >= 1) continue;
         return p;
@@ -517,13 +536,13 @@ static v3 ray_color(const rt_scene_desc* s, orc_rng* g, ray_t r, int depth, int 
 /* camera::get_ray, B1/camera.h:34-39 and B2/camera.h:38-45.
  * random_in_unit_disk (B1/vec3.h:145-151) builds vec3(random_double(-1,1), random_double(-1,1), 0):
  * g++ evaluates the arguments last to first, so the first draw lands in y.
- * Philox: block (site 0, try 0) = [jitter u, jitter v, disk x, disk y]; later disk tries use
- * words 0,1 of block (site 0, try k).                                                    */
+ * Philox: block 0 of site 0 = [jitter u, jitter v, disk x, disk y]; disk attempt k >= 1 uses
+ * block (k+1)/2: words 0,1 when k is odd, words 2,3 when k is even.                       */
 static ray_t get_ray(const rt_camera_desc* c, orc_rng* g, double s, double t, int has_time) {
     double px, py;
     for (uint32_t k = 0;; ++k) {
-        if (k > 0) rng_call(g, 0, k);
-        int sx = k == 0 ? 2 : 0, sy = k == 0 ? 3 : 1;
+        if ((k & 1u) == 1u) rng_call(g, 0, (k + 1u) / 2u);
+        int sx = (k & 1u) ? 0 : 2, sy = sx + 1;
         py = rng_draw_range(g, sy, -1, 1);
         px = rng_draw_range(g, sx, -1, 1);
         if (px * px + py * py + 0.0 * 0.0 >= 1) continue;

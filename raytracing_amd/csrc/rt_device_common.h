@@ -13,15 +13,18 @@
 namespace rtd {
 
 // ---------------------------------------------------------------- random numbers
-// One Philox4x32-10 block (Salmon et al., SC'11; Random123 constants) per
-// (pixel, sample, site, try); key = the 64-bit seed.
-//   site 0       camera ray of the sample: try 0 = [jitter u, jitter v, lens x, lens y],
-//                try k>0 = [lens x, lens y, -, -] (k-th retry of the unit-disk rejection loop,
-//                B1/vec3.h:145-151), try TRY_TIME = [shutter time, -, -, -]
-//   site 1+b     ray segment b: try k = [x, y, z, -] of the k-th unit-sphere rejection attempt
-//                (B1/vec3.h:114-120) or [Schlick draw, -, -, -] for a dielectric
-//                (B1/material.h:72); try TRY_MEDIUM+i = the draw of the constant_medium with node
-//                index i (B2/constant_medium.h:48) made while intersecting the segment.
+// Philox4x32-10 blocks (Salmon et al., SC'11; Random123 constants) with counter
+// (pixel, sample, site, block index); key = the 64-bit seed.  Philox is a sixth of all vector
+// instructions of a render kernel, so rejection loops use all four words of every block:
+//   site 0       camera ray of the sample: block 0 = [jitter u, jitter v, lens x, lens y]; attempt
+//                k >= 1 of the unit-disk rejection loop (B1/vec3.h:145-151) takes words 0,1 (k odd)
+//                or 2,3 (k even) of block (k+1)/2; block TRY_TIME = [shutter time, -, -, -]
+//   site 1+b     ray segment b: attempts 4g, 4g+1, 4g+2 of the unit-sphere rejection loop
+//                (B1/vec3.h:114-120) take words 0,1,2 = x,y,z of blocks 3g, 3g+1, 3g+2, attempt 4g+3
+//                takes the words 3 of those blocks (x, y, z in that order); a dielectric's Schlick
+//                draw (B1/material.h:72) is word 0 of block 0; block TRY_MEDIUM+i = the draw of the
+//                constant_medium with node index i (B2/constant_medium.h:48) made while
+//                intersecting the segment.
 // A draw is (word >> 1) * 2^-31: the 31-bit grid of rand()/(RAND_MAX+1.0) (B1/rtweekend.h:24-27).
 constexpr uint32_t TRY_TIME = 0x80000000u;
 constexpr uint32_t TRY_MEDIUM = 0x40000000u;

@@ -16,9 +16,14 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int
     const double t = (j + u01(w.y)) / (H - 1);
     double px = u_range(w.z, -1, 1), py = u_range(w.w, -1, 1);
     for (uint32_t k = 1; px * px + py * py + 0.0 * 0.0 >= 1; ++k) {  // random_in_unit_disk
-        w = philox4x32_10(pixel, sample, 0u, k, k0, k1);
-        px = u_range(w.x, -1, 1);
-        py = u_range(w.y, -1, 1);
+        if (k & 1u) {  // a new block every second attempt
+            w = philox4x32_10(pixel, sample, 0u, (k + 1u) >> 1, k0, k1);
+            px = u_range(w.x, -1, 1);
+            py = u_range(w.y, -1, 1);
+        } else {
+            px = u_range(w.z, -1, 1);
+            py = u_range(w.w, -1, 1);
+        }
     }
     const double rdx = C.lens_radius * px, rdy = C.lens_radius * py;
     const d3 cu{C.u[0], C.u[1], C.u[2]}, cv{C.v[0], C.v[1], C.v[2]};
@@ -35,9 +40,23 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int
 __device__ __forceinline__ d3 random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t site,
                                                     uint32_t k0, uint32_t k1) {
     d3 p{0, 0, 0};
+    uint32_t sx = 0, sy = 0, sz = 0;  // words 3 of the last three blocks: the fourth attempt of each group
     for (uint32_t k = 0; need; ++k) {
-        const u32x4 w = philox4x32_10(pixel, sample, site, k, k0, k1);
-        p = d3{u_range(w.x, -1, 1), u_range(w.y, -1, 1), u_range(w.z, -1, 1)};
+        uint32_t x, y, z;
+        if ((k & 3u) == 3u) {
+            x = sx;
+            y = sy;
+            z = sz;
+        } else {
+            const u32x4 w = philox4x32_10(pixel, sample, site, 3u * (k >> 2) + (k & 3u), k0, k1);
+            x = w.x;
+            y = w.y;
+            z = w.z;
+            sx = (k & 3u) == 0u ? w.w : sx;
+            sy = (k & 3u) == 1u ? w.w : sy;
+            sz = (k & 3u) == 2u ? w.w : sz;
+        }
+        p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
         if (!(len2(p) >= 1)) need = false;
     }
     return p;
