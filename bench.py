@@ -36,6 +36,27 @@ def algorithmic_flop(n_objects, rays, samples):
     return rays * (n_objects * 23.0 + 60.0) + samples * 40.0
 
 
+def profiled_traffic(width, height, spp, depth):
+    """HBM-side bytes per launch of k_render_spheres from the newest committed rocprofv3 counter summary
+    (profiles/*_bench_c2.json: FETCH_SIZE + WRITE_SIZE passes of this same command, see tools/profile_bench.sh),
+    or None when there is none for this frame size.  The counters are L2 memory-side requests: almost all of
+    them are the 64-bit accumulation atomics, which the 256 MB Infinity Cache absorbs."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_c2.json"))):
+        try:
+            with open(path) as fp:
+                prof = json.load(fp)
+            cfg = prof["bench_line_under_profiler"]["config"]
+            c = prof["counters_per_launch"]
+            if (cfg["width"], cfg["height"], cfg["spp"], cfg["max_depth"]) != (width, height, spp, depth):
+                continue
+            best = {"bytes": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "source": os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return best
+
+
 def cpu_baseline(scene_path):
     """The reference renderer itself (oracle/_ref/ref_b1, compiled from the unmodified sources in the
     development container), one thread, on a bounded sample of the same workload; falls back to the
@@ -204,6 +225,7 @@ def main():
         k_ms = st["kernel_ms"] / max(1, st["kernel_launches"]) if n_slots == 1 else dt / args.steps * 1e3
         flop_per_launch = algorithmic_flop(n_objects, st["rays"], st["samples"]) / max(1, st["kernel_launches"])
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = profiled_traffic(W, H, spp, args.depth)
         out = {
             "metric": "Msamples/sec (paths x spp / s), One-Weekend final scene",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,12 +238,14 @@ def main():
                        "frames_in_flight": n_slots},
             "mrays_per_s": rays / dt / 1e6, "rays_per_sample": rays / max(1, samples), "nan_samples": bad,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "k_render_spheres", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch,
                          "note": "FP32 vector roofline; flop = reference algorithm (flat list, 23 flop per "
-                                 "sphere test); HBM traffic per launch is the 23 MB accumulation buffer only, "
-                                 "see profiles/"},
+                                 "sphere test); traffic = L2 memory-side bytes per launch from the committed "
+                                 "counter passes (64-bit accumulation atomics, absorbed by the Infinity Cache; "
+                                 "algorithmic bytes are the 23 MB frame)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path)
