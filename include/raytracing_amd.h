@@ -59,6 +59,8 @@ enum {
     RT_NODE_TRANSLATE = 9,     /* B2/hittable.h:31-41   child0=ptr p[0..2]=offset                     */
     RT_NODE_ROTATE_Y = 10,     /* B2/hittable.h:62-79   child0=ptr p[0]=sin_theta p[1]=cos_theta
                                                          p[2]=hasbox p[3..5]=bbox.min p[6..8]=bbox.max */
+    RT_NODE_FLIP_FACE = 12,    /* flip_face of "The Rest Of Your Life" (public book text; the reference repository
+                                  holds no book-3 code): child0=ptr; hit() of the child with front_face negated  */
     RT_NODE_MEDIUM = 11        /* B2/constant_medium.h:10-28 child0=boundary p[0]=neg_inv_density,
                                                          material = the isotropic phase function       */
 };
@@ -137,7 +139,9 @@ typedef struct rt_scene_desc {
     const rt_perlin* perlins;
     const rt_image* images;
     int32_t sky_mode;
-    int32_t reserved;
+    int32_t lights_plus1; /* 0 = none; else 1 + index of a RT_NODE_LIST (not reachable from root) whose children
+                             are the shapes light is sampled towards under RT_RENDER_IMPORTANCE: RT_NODE_XZ_RECT
+                             and RT_NODE_SPHERE, in world space (book 3's `lights` argument of ray_color)      */
     double background[3];
 } rt_scene_desc;
 
@@ -173,7 +177,12 @@ typedef struct rt_render_params {
 
 enum {
     RT_RENDER_DEFAULT = 0,
-    RT_RENDER_EXACT_ONLY = 1 /* validation: skip the float screening pass, test every object in double */
+    RT_RENDER_EXACT_ONLY = 1, /* validation: skip the float screening pass, test every object in double */
+    RT_RENDER_IMPORTANCE = 2  /* ray_color of "The Rest Of Your Life" (final listing of the public book text; no
+                                 reference code exists for it, so parity for this mode is unpinned): lambertian
+                                 surfaces sample a 50/50 mixture of the cosine density and the density towards
+                                 the scene's light shapes, metal and dielectric are specular, lights emit from
+                                 their front face only.  Needs lights_plus1 != 0; scene-graph kernels only      */
 };
 
 /* Colour sums are accumulated in 64-bit fixed point so that the sum over samples does not

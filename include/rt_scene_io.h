@@ -9,6 +9,7 @@
  * Layout (all integers int32, all reals IEEE double, no padding beyond the structs' own):
  *   char   magic[8]  = "RTSCENE1"
  *   int32  root, n_nodes, n_children, n_materials, n_textures, n_perlins, n_images, sky_mode
+ *          (the last word also carries lights_plus1 in bits 8..31; files without lights have 0 there)
  *   double background[3]
  *   rt_node     nodes[n_nodes]
  *   int32       children[n_children]
@@ -63,7 +64,7 @@ static inline int rt_scene_file_write(const char* path, const rt_scene_desc* s) 
     FILE* fp = fopen(path, "wb");
     if (!fp) return RT_ERR_INVALID_ARGUMENT;
     int32_t head[8] = {s->root,       s->n_nodes,   s->n_children, s->n_materials,
-                       s->n_textures, s->n_perlins, s->n_images,   s->sky_mode};
+                       s->n_textures, s->n_perlins, s->n_images,   (int32_t)((s->sky_mode & 0xFF) | (s->lights_plus1 << 8))};
     int ok = fwrite("RTSCENE1", 1, 8, fp) == 8;
     ok = ok && fwrite(head, sizeof(int32_t), 8, fp) == 8;
     ok = ok && fwrite(s->background, sizeof(double), 3, fp) == 3;
@@ -108,7 +109,8 @@ static inline int rt_scene_file_read(const char* path, rt_scene_file* f) {
         f->desc.n_textures = head[4];
         f->desc.n_perlins = head[5];
         f->desc.n_images = head[6];
-        f->desc.sky_mode = head[7];
+        f->desc.sky_mode = head[7] & 0xFF;
+        f->desc.lights_plus1 = (int32_t)((uint32_t)head[7] >> 8);
     }
     ok = ok && fread(f->desc.background, sizeof(double), 3, fp) == 3;
     ok = ok && rt_scene_file_read_array_(fp, (void**)&f->nodes, sizeof(rt_node), f->desc.n_nodes);

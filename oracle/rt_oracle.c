@@ -14,8 +14,13 @@
  * for bit (colour sums and P3 output of the config-1 scene, reduced config-2 renders,
  * first-hit ids; the fixtures under tests/golden are produced by the unmodified reference,
  * see oracle/make_golden.py).  With rng_mode = ORC_RNG_PHILOX the same code draws from
- * Philox4x32-10 keyed by (pixel, sample, site, try), which is what the GPU kernels do, so
+ * Philox4x32-10 keyed by (pixel, sample, site, block), which is what the GPU kernels do, so
  * GPU output can be compared number for number.
+ *
+ * One part is PARITY UNPINNED: ray_color_pdf and its helpers (RT_RENDER_IMPORTANCE, "The Rest
+ * Of Your Life").  The reference repository holds no book-3 code, so they restate the public
+ * book text and no output of the reference exists to check them against; tests/test_book3.py
+ * checks them against plain path tracing of the same world instead.
  *
  * Build: gcc -O2 -ffp-contract=off (no -ffast-math, no -march): see oracle/Makefile.
  */
@@ -314,6 +319,10 @@ static int hit_node(hit_ctx* cx, int idx, const ray_t* r, double t_min, double t
         set_face_normal(rec, &rotated, normal);
         return 1;
     }
+    case RT_NODE_FLIP_FACE: /* flip_face::hit of book 3 (public text): the child's record, front_face negated */
+        if (!hit_node(cx, n->child0, r, t_min, t_max, rec)) return 0;
+        rec->front_face = !rec->front_face;
+        return 1;
     case RT_NODE_MEDIUM: { /* B2/constant_medium.h:30-66 */
         hit_record rec1 = *rec, rec2 = *rec;
         if (!hit_node(cx, n->child0, r, -INFINITY, INFINITY, &rec1)) return 0;
@@ -533,6 +542,149 @@ static v3 ray_color(const rt_scene_desc* s, orc_rng* g, ray_t r, int depth, int 
     return acc;
 }
 
+/* ------------------------------------------------------------------ "The Rest Of Your Life"
+ * There is no book-3 code in the reference repository (its third directory is a copy of book 2), so this
+ * part restates the final listing of the PUBLIC BOOK TEXT (Ray Tracing: The Rest of Your Life, v3.2) and
+ * its parity is UNPINNED: no output of the reference exists to check it against.
+ *
+ * Philox words of a lambertian bounce at segment site s: block 0 = [mixture choice, light index,
+ * first and second number of the chosen sampler]; metal and dielectric draw as in books 1/2.   */
+typedef struct { v3 u, v, w; } onb_t;
+static onb_t onb_from_w(v3 n) { /* onb::build_from_w */
+    onb_t o;
+    o.w = vunit(n);
+    v3 a = (fabs(o.w.e[0]) > 0.9) ? V(0, 1, 0) : V(1, 0, 0);
+    o.v = vunit(vcross(o.w, a));
+    o.u = vcross(o.w, o.v);
+    return o;
+}
+static v3 onb_local(const onb_t* o, v3 a) {
+    return vadd(vadd(vscale(a.e[0], o->u), vscale(a.e[1], o->v)), vscale(a.e[2], o->w));
+}
+/* hittable::pdf_value of xz_rect and sphere */
+static double shape_pdf_value(const rt_scene_desc* s, const rt_node* n, v3 origin, v3 v) {
+    hit_record rec;
+    memset(&rec, 0, sizeof(rec));
+    ray_t r = {origin, v, 0.0};
+    if (n->kind == RT_NODE_XZ_RECT) {
+        if (!hit_rect(n, 1, 0, 2, &r, 0.001, INFINITY, &rec)) return 0;
+        double area = (n->p[1] - n->p[0]) * (n->p[3] - n->p[2]);
+        double distance_squared = rec.t * rec.t * vlen2(v);
+        double cosine = fabs(vdot(v, rec.normal) / vlen(v));
+        return distance_squared / (cosine * area);
+    }
+    if (n->kind == RT_NODE_SPHERE) {
+        v3 center = V(n->p[0], n->p[1], n->p[2]);
+        if (!hit_sphere_at(center, n->p[3], n->material, s->n_textures > 0, &r, 0.001, INFINITY, &rec)) return 0;
+        double cos_theta_max = sqrt(1 - n->p[3] * n->p[3] / vlen2(vsub(center, origin)));
+        double solid_angle = 2 * ORC_PI * (1 - cos_theta_max);
+        return 1 / solid_angle;
+    }
+    return 0;
+}
+/* hittable::random of xz_rect and sphere; r1 = word 2, r2 = word 3 of the current block */
+static v3 shape_random(const rt_node* n, v3 origin, orc_rng* g) {
+    if (n->kind == RT_NODE_XZ_RECT) { /* point3(random_double(x0,x1), k, random_double(z0,z1)): z is drawn first */
+        double z = rng_draw_range(g, 3, n->p[2], n->p[3]);
+        double x = rng_draw_range(g, 2, n->p[0], n->p[1]);
+        return vsub(V(x, n->p[4], z), origin);
+    }
+    v3 center = V(n->p[0], n->p[1], n->p[2]);
+    v3 direction = vsub(center, origin);
+    double distance_squared = vlen2(direction);
+    onb_t uvw = onb_from_w(direction);
+    double r1 = rng_draw(g, 2), r2 = rng_draw(g, 3); /* random_to_sphere */
+    double z = 1 + r2 * (sqrt(1 - n->p[3] * n->p[3] / distance_squared) - 1);
+    double phi = 2 * ORC_PI * r1;
+    double x = cos(phi) * sqrt(1 - z * z);
+    double y = sin(phi) * sqrt(1 - z * z);
+    return onb_local(&uvw, V(x, y, z));
+}
+/* hittable_list::pdf_value over the light shapes */
+static double lights_pdf_value(const rt_scene_desc* s, v3 origin, v3 v) {
+    const rt_node* L = &s->nodes[s->lights_plus1 - 1];
+    double weight = 1.0 / L->child1;
+    double sum = 0.0;
+    for (int i = 0; i < L->child1; ++i)
+        sum += weight * shape_pdf_value(s, &s->nodes[s->children[L->child0 + i]], origin, v);
+    return sum;
+}
+
+/* ray_color of the book's final listing.  ORC_ASSOC_REFERENCE replays the recursion
+ *     emitted + attenuation * scattering_pdf * ray_color(...) / pdf_val      (diffuse)
+ *     attenuation * ray_color(...)                                            (specular)
+ * from a stack; ORC_ASSOC_FORWARD keeps  L += T*e,  T *= (1/pdf_val) * (scattering_pdf * attenuation). */
+static v3 ray_color_pdf(const rt_scene_desc* s, orc_rng* g, ray_t r, int depth, int assoc, uint64_t* rays) {
+    static _Thread_local v3 att_stack[ORC_MAX_DEPTH], emi_stack[ORC_MAX_DEPTH];
+    static _Thread_local double spdf_stack[ORC_MAX_DEPTH], pdf_stack[ORC_MAX_DEPTH];
+    static _Thread_local int spec_stack[ORC_MAX_DEPTH];
+    int n = 0;
+    v3 L_end = V(0, 0, 0), T = V(1, 1, 1), L = V(0, 0, 0);
+    for (uint32_t bounce = 0;; ++bounce) {
+        if (depth <= 0) break;
+        hit_record rec;
+        memset(&rec, 0, sizeof(rec));
+        const uint32_t site = 1 + bounce;
+        hit_ctx cx = {s, g, site};
+        ++*rays;
+        if (!hit_node(&cx, s->root, &r, 0.001, INFINITY, &rec)) {
+            L_end = V(s->background[0], s->background[1], s->background[2]);
+            break;
+        }
+        const rt_material* m = &s->materials[rec.mat];
+        /* diffuse_light::emitted: the front face only */
+        v3 e = V(0, 0, 0);
+        if (m->kind == RT_MAT_DIFFUSE_LIGHT && rec.front_face) e = texture_value(s, m->texture, rec.u, rec.v, rec.p);
+        if (m->kind == RT_MAT_METAL || m->kind == RT_MAT_DIELECTRIC) { /* srec.is_specular */
+            v3 attenuation;
+            ray_t scattered;
+            scatter(s, g, site, &r, &rec, &attenuation, &scattered); /* metal: the ray is followed whatever its side */
+            att_stack[n] = attenuation; emi_stack[n] = e; spec_stack[n] = 1; spdf_stack[n] = pdf_stack[n] = 1; ++n;
+            T = vmul(T, attenuation);
+            r = scattered;
+            --depth;
+            continue;
+        }
+        if (m->kind != RT_MAT_LAMBERTIAN) { /* lights (and anything that does not scatter) end the path */
+            L_end = e;
+            break;
+        }
+        v3 attenuation = texture_value(s, m->texture, rec.u, rec.v, rec.p);
+        onb_t uvw = onb_from_w(rec.normal); /* cosine_pdf(rec.normal) */
+        rng_call(g, site, 0);
+        v3 direction;
+        if (rng_draw(g, 0) < 0.5) { /* mixture_pdf::generate: p[0] = hittable_pdf(lights, rec.p) */
+            const rt_node* Ls = &s->nodes[s->lights_plus1 - 1];
+            int idx = (int)rng_draw_range(g, 1, 0, (Ls->child1 - 1) + 1); /* random_int(0, size-1) */
+            direction = shape_random(&s->nodes[s->children[Ls->child0 + idx]], rec.p, g);
+        } else { /* random_cosine_direction */
+            double r1 = rng_draw(g, 2), r2 = rng_draw(g, 3);
+            double z = sqrt(1 - r2);
+            double phi = 2 * ORC_PI * r1;
+            double x = cos(phi) * sqrt(r2);
+            double y = sin(phi) * sqrt(r2);
+            direction = onb_local(&uvw, V(x, y, z));
+        }
+        ray_t scattered = {rec.p, direction, r.tm};
+        double cosine_w = vdot(vunit(direction), uvw.w);
+        double cos_pdf = (cosine_w <= 0) ? 0 : cosine_w / ORC_PI;
+        double pdf_val = 0.5 * lights_pdf_value(s, rec.p, direction) + 0.5 * cos_pdf;
+        double cosine_n = vdot(rec.normal, vunit(direction)); /* lambertian::scattering_pdf */
+        double spdf = cosine_n < 0 ? 0 : cosine_n / ORC_PI;
+        att_stack[n] = attenuation; emi_stack[n] = e; spec_stack[n] = 0; spdf_stack[n] = spdf; pdf_stack[n] = pdf_val; ++n;
+        T = vmul(T, vscale(1 / pdf_val, vscale(spdf, attenuation)));
+        r = scattered;
+        --depth;
+    }
+    if (assoc == ORC_ASSOC_FORWARD) return vadd(L, vmul(T, L_end));
+    v3 acc = L_end;
+    for (int k = n - 1; k >= 0; --k) {
+        if (spec_stack[k]) acc = vmul(att_stack[k], acc);
+        else acc = vadd(emi_stack[k], vdiv(vmul(vscale(spdf_stack[k], att_stack[k]), acc), pdf_stack[k]));
+    }
+    return acc;
+}
+
 /* camera::get_ray, B1/camera.h:34-39 and B2/camera.h:38-45.
  * random_in_unit_disk (B1/vec3.h:145-151) builds vec3(random_double(-1,1), random_double(-1,1), 0):
  * g++ evaluates the arguments last to first, so the first draw lands in y.
@@ -630,7 +782,9 @@ static void render_rows(render_job* jb) {
                 double u = (i + rng_draw(&g, 0)) / (W - 1);
                 double v = (j + rng_draw(&g, 1)) / (H - 1);
                 ray_t r = get_ray(jb->cam, &g, u, v, jb->has_time);
-                v3 c = ray_color(jb->s, &g, r, prm->max_depth, jb->assoc, &jb->rays);
+                v3 c = (prm->flags & RT_RENDER_IMPORTANCE)
+                           ? ray_color_pdf(jb->s, &g, r, prm->max_depth, jb->assoc, &jb->rays)
+                           : ray_color(jb->s, &g, r, prm->max_depth, jb->assoc, &jb->rays);
                 pixel_color = vadd(pixel_color, c);
                 if (jb->fixed) {
                     if (isfinite(c.e[0]) && isfinite(c.e[1]) && isfinite(c.e[2])) {
@@ -662,6 +816,7 @@ static void* render_thread(void* p) {
 int orc_render(const rt_scene_desc* s, const rt_camera_desc* cam, const rt_render_params* prm, int rng_mode,
                int assoc, int has_time, int n_threads, double* accum, int64_t* fixed, uint64_t* stats_out) {
     if (!s || !cam || !prm || prm->max_depth > ORC_MAX_DEPTH) return RT_ERR_INVALID_ARGUMENT;
+    if ((prm->flags & RT_RENDER_IMPORTANCE) && s->lights_plus1 <= 0) return RT_ERR_INVALID_ARGUMENT;
     if (n_threads < 1) n_threads = 1;
     if (rng_mode == ORC_RNG_RAND) n_threads = 1;
     if (n_threads > prm->height) n_threads = prm->height > 0 ? prm->height : 1;

@@ -24,7 +24,8 @@ RT_ERR_OUT_OF_MEMORY = 6
 RT_ERR_LIMIT = 7
 
 (RT_NODE_SPHERE, RT_NODE_MOVING_SPHERE, RT_NODE_XY_RECT, RT_NODE_XZ_RECT, RT_NODE_YZ_RECT, RT_NODE_BOX,
- RT_NODE_LIST, RT_NODE_BVH, RT_NODE_TRANSLATE, RT_NODE_ROTATE_Y, RT_NODE_MEDIUM) = range(1, 12)
+ RT_NODE_LIST, RT_NODE_BVH, RT_NODE_TRANSLATE, RT_NODE_ROTATE_Y, RT_NODE_MEDIUM, RT_NODE_FLIP_FACE) = range(1, 13)
+RT_RENDER_EXACT_ONLY, RT_RENDER_IMPORTANCE = 1, 2
 (RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT_ISOTROPIC) = range(1, 6)
 (RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE) = range(1, 5)
 RT_SKY_GRADIENT, RT_SKY_BACKGROUND = 0, 1
@@ -60,7 +61,7 @@ class rt_scene_desc(C.Structure):
                 ("nodes", C.POINTER(rt_node)), ("children", C.POINTER(C.c_int32)),
                 ("materials", C.POINTER(rt_material)), ("textures", C.POINTER(rt_texture)),
                 ("perlins", C.POINTER(rt_perlin)), ("images", C.POINTER(rt_image)),
-                ("sky_mode", C.c_int32), ("reserved", C.c_int32), ("background", C.c_double * 3)]
+                ("sky_mode", C.c_int32), ("lights_plus1", C.c_int32), ("background", C.c_double * 3)]
 
 
 class rt_camera_desc(C.Structure):
@@ -105,6 +106,7 @@ class Scene:
     images: list = field(default_factory=list)  # list of uint8 arrays shaped (h, w, 3)
     sky_mode: int = RT_SKY_GRADIENT
     background: tuple = (0.0, 0.0, 0.0)
+    lights_plus1: int = 0  # 1 + index of the list node holding the light shapes (importance sampling), 0 = none
 
     def desc(self) -> rt_scene_desc:
         """Build an rt_scene_desc that points into this object's arrays (keep `self` alive)."""
@@ -129,6 +131,7 @@ class Scene:
             self._image_structs[k].rgb = C.cast(im.ctypes.data, C.POINTER(C.c_uint8)) if im.size else None
         d.images = C.cast(self._image_structs, C.POINTER(rt_image)) if self.images else None
         d.sky_mode = int(self.sky_mode)
+        d.lights_plus1 = int(self.lights_plus1)
         d.background[:] = [float(x) for x in self.background]
         return d
 
@@ -167,14 +170,14 @@ def load_scene(path) -> Scene:
         images.append(take(np.uint8, 3 * w * h).reshape(h, w, 3))
     if off != len(blob):
         raise ValueError(f"{path}: {len(blob) - off} trailing bytes")
-    return Scene(root, nodes, children, materials, textures, perlins, images, sky, background)
+    return Scene(root, nodes, children, materials, textures, perlins, images, sky & 0xFF, background, (sky & 0xFFFFFFFF) >> 8)
 
 
 def save_scene(path, s: Scene) -> None:
     with open(path, "wb") as fp:
         fp.write(b"RTSCENE1")
         fp.write(struct.pack("<8i", s.root, len(s.nodes), len(s.children), len(s.materials), len(s.textures),
-                             len(s.perlins), len(s.images), s.sky_mode))
+                             len(s.perlins), len(s.images), (s.sky_mode & 0xFF) | (s.lights_plus1 << 8)))
         fp.write(struct.pack("<3d", *s.background))
         for a in (s.nodes, s.children, s.materials, s.textures, s.perlins):
             fp.write(a.tobytes())
@@ -183,9 +186,9 @@ def save_scene(path, s: Scene) -> None:
             fp.write(im.tobytes())
 
 
-def render_params(width, height, spp, max_depth=50, seed=1, sample_begin=0) -> rt_render_params:
+def render_params(width, height, spp, max_depth=50, seed=1, sample_begin=0, flags=0) -> rt_render_params:
     p = rt_render_params()
     p.width, p.height = int(width), int(height)
     p.sample_begin, p.sample_count = int(sample_begin), int(spp)
-    p.max_depth, p.flags, p.seed = int(max_depth), 0, int(seed)
+    p.max_depth, p.flags, p.seed = int(max_depth), int(flags), int(seed)
     return p

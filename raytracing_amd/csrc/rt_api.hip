@@ -30,6 +30,7 @@ struct rt_context {
     int num_cus = 0;
     int blocks_per_cu_spheres = 0;
     int blocks_per_cu_scene = 0;
+    bool graph_can_importance = false;  // the uploaded world has light shapes and no isotropic material
     int blocks_override = 0;
     std::string detail;
     bool exact_only = false;     // validation: bypass the float screen
@@ -199,7 +200,8 @@ struct GraphCheck {
         }
         case RT_NODE_TRANSLATE:
         case RT_NODE_ROTATE_Y:
-            if (xf_depth + 1 > XF_DEPTH_CAP) { bad(RT_ERR_LIMIT, "more than 4 nested translate / rotate_y levels"); return 0; }
+        case RT_NODE_FLIP_FACE:  // a wrapper like the instances: the ray passes unchanged, the record's face flips
+            if (xf_depth + 1 > XF_DEPTH_CAP) { bad(RT_ERR_LIMIT, "more than 4 nested translate / rotate_y / flip_face levels"); return 0; }
             return std::max(2, 1 + walk(n.child0, idx, xf_depth + 1, top));
         case RT_NODE_MEDIUM: {
             material_ok(n.material);
@@ -380,6 +382,9 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             d.p[0] = n.p[0];
             d.p[1] = n.p[1];
             break;
+        case RT_NODE_FLIP_FACE:
+            d.a = n.child0;
+            break;
         case RT_NODE_MEDIUM:
             d.a = n.material;
             d.b = n.child0;
@@ -427,6 +432,16 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     if ((rc = to_device(ctx, texs, &G.textures)) != RT_OK) return rc;
     if ((rc = to_device(ctx, perlins, &G.perlins)) != RT_OK) return rc;
     if ((rc = to_device(ctx, images, &G.images)) != RT_OK) return rc;
+    std::vector<int32_t> lights;
+    bool isotropic = false;
+    for (int i = 0; i < sc->n_materials; ++i) isotropic = isotropic || sc->materials[i].kind == RT_MAT_ISOTROPIC;
+    if (sc->lights_plus1 != 0) {
+        const rt_node& L = sc->nodes[sc->lights_plus1 - 1];
+        lights.assign(sc->children + L.child0, sc->children + L.child0 + L.child1);
+    }
+    G.n_lights = (int32_t)lights.size();
+    for (int i = 0; i < MAX_LIGHT_SHAPES; ++i) G.lights[i] = i < G.n_lights ? lights[(size_t)i] : -1;
+    ctx->graph_can_importance = G.n_lights > 0 && !isotropic;
     G.root = sc->root;
     G.n_nodes = sc->n_nodes;
     G.sky_mode = sc->sky_mode;
@@ -440,7 +455,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
         if (std::strcmp(v, "all") == 0) features = ~0;
     }
     G.features = features;
-    ctx->blocks_per_cu_scene = render_scene_blocks_per_cu(features);
+    ctx->blocks_per_cu_scene = render_scene_blocks_per_cu(features, false);
     ctx->path = PATH_GRAPH;
     return RT_OK;
 }
@@ -545,13 +560,28 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     chk.visited.assign((size_t)sc->n_nodes, 0);
     const int stack_need = 1 + chk.walk(sc->root, -1, 0, -1);
     if (chk.code != RT_OK) return fail(ctx, chk.code, chk.error);
+    if (sc->lights_plus1 != 0) {  // the shapes light is sampled towards (RT_RENDER_IMPORTANCE)
+        const int li = sc->lights_plus1 - 1;
+        if (li < 0 || li >= sc->n_nodes || sc->nodes[li].kind != RT_NODE_LIST || chk.visited[li])
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "lights_plus1 must name a list node outside the world graph");
+        const rt_node& L = sc->nodes[li];
+        if (!chk.child_range_ok(L)) return fail(ctx, chk.code, chk.error);
+        if (L.child1 < 1 || L.child1 > MAX_LIGHT_SHAPES) return fail(ctx, RT_ERR_LIMIT, "1 to 16 light shapes");
+        for (int i = 0; i < L.child1; ++i) {
+            const int c = sc->children[L.child0 + i];
+            if (c < 0 || c >= sc->n_nodes || chk.visited[c] ||
+                (sc->nodes[c].kind != RT_NODE_XZ_RECT && sc->nodes[c].kind != RT_NODE_SPHERE))
+                return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "light shapes must be xz_rect or sphere nodes of their own");
+        }
+    }
     if (stack_need > STACK_CAP)
         return fail(ctx, RT_ERR_LIMIT, "traversal needs " + std::to_string(stack_need) + " stack slots, limit " + std::to_string(STACK_CAP));
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    int rc = (!ctx->force_graph && is_book1_sphere_list(sc)) ? upload_sphere_list(ctx, sc) : upload_graph(ctx, sc, chk);
+    int rc = (!ctx->force_graph && sc->lights_plus1 == 0 && is_book1_sphere_list(sc)) ? upload_sphere_list(ctx, sc)
+                                                                                        : upload_graph(ctx, sc, chk);
     if (rc != RT_OK) free_scene(ctx);
     return rc;
 }
@@ -603,7 +633,12 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     const int64_t items = (int64_t)plan.levels * p->width * p->height;
     if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
     const bool spheres = ctx->path == PATH_SPHERE_LIST;
-    int per_cu = spheres ? ctx->blocks_per_cu_spheres : ctx->blocks_per_cu_scene;
+    const bool importance = (p->flags & RT_RENDER_IMPORTANCE) != 0;
+    if (importance && (spheres || !ctx->graph_can_importance))
+        return fail(ctx, RT_ERR_UNSUPPORTED_SCENE,
+                    "RT_RENDER_IMPORTANCE needs a world uploaded with light shapes (lights_plus1) and without isotropic materials");
+    int per_cu = spheres ? ctx->blocks_per_cu_spheres
+                         : (importance ? render_scene_blocks_per_cu(ctx->graph.features, true) : ctx->blocks_per_cu_scene);
     if (ctx->blocks_override) per_cu = ctx->blocks_override;
     int blocks = ctx->num_cus * per_cu;
     const int64_t max_useful = (items + 255) / 256;
@@ -666,6 +701,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);
+        A.importance = importance ? 1 : 0;
         A.accum = d_accum_fixed;
         A.item_counter = ctx->d_counter;
         A.stats = ctx->d_stats;

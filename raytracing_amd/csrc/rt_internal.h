@@ -101,6 +101,7 @@ struct ImageDev {
     int32_t width, height;
     const uint8_t* rgb;
 };
+constexpr int MAX_LIGHT_SHAPES = 16;
 struct SceneDev {
     int32_t root;
     int32_t n_nodes;
@@ -114,6 +115,8 @@ struct SceneDev {
     const rt_perlin* perlins;
     const ImageDev* images;
     int32_t sky_mode;
+    int32_t n_lights;                  // light shapes sampled under RT_RENDER_IMPORTANCE
+    int32_t lights[MAX_LIGHT_SHAPES];  // their node ids (xz_rect or sphere, world space)
     int32_t features;  // F_* bits of rt_kernels_scene.hip the world needs
     double background[3];
 };
@@ -129,6 +132,7 @@ struct SceneRenderArgs {
     int32_t item_cap;
     uint32_t n_items;
     uint32_t key0, key1;
+    int32_t importance;  // 1: ray_color of book 3 (RT_RENDER_IMPORTANCE)
     int64_t* accum;
     uint32_t* item_counter;
     uint64_t* stats;
@@ -141,7 +145,7 @@ struct SceneFirstHitArgs {
 };
 hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream);
 hipError_t launch_first_hit_scene(const SceneFirstHitArgs& args, hipStream_t stream);
-int render_scene_blocks_per_cu(int features);
+int render_scene_blocks_per_cu(int features, bool importance);
 #ifdef RT_SCENE_PROBE
 void scene_probe_dump();  // debug build: prints and clears the traversal counters
 #endif

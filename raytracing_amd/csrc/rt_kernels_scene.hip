@@ -42,6 +42,7 @@ enum : int {
     F_NOISE = 32,    // Perlin noise textures
     F_IMAGE = 64,    // image textures
     F_ALL = 127,
+    F_IS = 128,      // ray_color of book 3: light sampled by importance (RT_RENDER_IMPORTANCE); not part of F_ALL
 };
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
 
@@ -53,6 +54,7 @@ __device__ __forceinline__ double comp(d3 v, int axis) { return axis == 0 ? v.x 
 
 // Ray handed to the child of a translate / rotate_y node (B2/hittable.h:44, 114-123).
 __device__ __forceinline__ Ray xf_apply(const SceneNode& n, Ray r) {
+    if (n.kind == RT_NODE_FLIP_FACE) return r;  // flip_face hands its ray on unchanged
     if (n.kind == RT_NODE_TRANSLATE) {
         r.o = r.o - d3{n.p[0], n.p[1], n.p[2]};
         return r;
@@ -347,7 +349,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     if ((int)tag + 1 < n.b) stack[(sp++) * 64 + lane] = (uint32_t)e | ((tag + 1u) << 16);
                     stack[(sp++) * 64 + lane] = (uint32_t)S.children[n.a + (int)tag];
                 }
-            } else if ((F & F_XF) != 0 && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y)) {
+            } else if ((F & F_XF) != 0 && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y || kind == RT_NODE_FLIP_FACE)) {
                 const bool rotates = kind == RT_NODE_ROTATE_Y;
                 stack[(sp++) * 64 + lane] = (uint32_t)e | ((rotates ? END_XF : END_XF_TRANSLATE) << 16);
                 stack[(sp++) * 64 + lane] = (uint32_t)n.a;
@@ -436,7 +438,9 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
     for (int x = h.xf, lvl = 0; x >= 0 && lvl < XF_DEPTH_CAP; x = S.parent_xf[x], ++lvl) {
         const SceneNode xn = S.nodes[x];
         const Ray child_ray = ray_in<F>(S, x, w);
-        if (xn.kind == RT_NODE_TRANSLATE) {
+        if (xn.kind == RT_NODE_FLIP_FACE) {
+            s.front_face = !s.front_face;
+        } else if (xn.kind == RT_NODE_TRANSLATE) {
             s.p = s.p + d3{xn.p[0], xn.p[1], xn.p[2]};
             set_face_normal(s, child_ray, s.normal);
         } else {
@@ -530,6 +534,92 @@ __device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& 
     return d3{0, 0, 0};
 }
 
+// ---------------------------------------------------------------- "The Rest Of Your Life"
+// Restated from the final listing of the public book text (the reference repository holds no book-3 code):
+// orthonormal basis, pdf_value / random of the two shapes a light list may hold, cosine density.
+struct Onb {
+    d3 u, v, w;
+};
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+    return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Onb onb_from_w(d3 n) {  // onb::build_from_w
+    Onb o;
+    o.w = unit_vector(n);
+    const d3 a = (fabs(o.w.x) > 0.9) ? d3{0, 1, 0} : d3{1, 0, 0};
+    o.v = unit_vector(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+__device__ __forceinline__ d3 onb_local(const Onb& o, d3 a) { return a.x * o.u + a.y * o.v + a.z * o.w; }
+
+constexpr double PI_D = 3.14159265358979323846;
+
+// hittable::pdf_value of xz_rect and sphere
+__device__ __forceinline__ double shape_pdf_value(const SceneNode& n, d3 origin, d3 v) {
+    const Ray r{origin, v};
+    double t, ua, vb;
+    if (n.kind == RT_NODE_XZ_RECT) {
+        if (!hit_rect_raw(1, 0, 2, n.p[0], n.p[1], n.p[2], n.p[3], n.p[4], r, 0.001, __builtin_inf(), t, ua, vb)) return 0.0;
+        const d3 outward{0, 1, 0};
+        const d3 normal = dot(v, outward) < 0 ? outward : -outward;  // set_face_normal
+        const double area = (n.p[1] - n.p[0]) * (n.p[3] - n.p[2]);
+        const double distance_squared = t * t * len2(v);
+        const double cosine = fabs(dot(v, normal) / sqrt(len2(v)));
+        return distance_squared / (cosine * area);
+    }
+    const d3 center{n.p[0], n.p[1], n.p[2]};
+    if (!hit_sphere(center, n.p[3], r, len2(v), 0.001, __builtin_inf(), t)) return 0.0;
+    const double cos_theta_max = sqrt(1 - n.p[3] * n.p[3] / len2(center - origin));
+    const double solid_angle = 2 * PI_D * (1 - cos_theta_max);
+    return 1 / solid_angle;
+}
+// hittable::random of xz_rect and sphere from the third and fourth word of the bounce's block
+__device__ __forceinline__ d3 shape_random(const SceneNode& n, d3 origin, uint32_t w2, uint32_t w3) {
+    if (n.kind == RT_NODE_XZ_RECT) {
+        const double z = u_range(w3, n.p[2], n.p[3]);
+        const double x = u_range(w2, n.p[0], n.p[1]);
+        return d3{x, n.p[4], z} - origin;
+    }
+    const d3 center{n.p[0], n.p[1], n.p[2]};
+    const d3 direction = center - origin;
+    const double distance_squared = len2(direction);
+    const Onb uvw = onb_from_w(direction);
+    const double r1 = u01(w2), r2 = u01(w3);  // random_to_sphere
+    const double z = 1 + r2 * (sqrt(1 - n.p[3] * n.p[3] / distance_squared) - 1);
+    const double phi = 2 * PI_D * r1;
+    const double x = cos(phi) * sqrt(1 - z * z);
+    const double y = sin(phi) * sqrt(1 - z * z);
+    return onb_local(uvw, d3{x, y, z});
+}
+// One lambertian bounce of the book's ray_color: direction from the 50/50 mixture of the light density and the
+// cosine density; returns  (1 / pdf_val) * (scattering_pdf * attenuation)  as the factor of the throughput.
+__device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 normal, d3 attenuation, const RngCtx& g, d3& dir) {
+    const Onb uvw = onb_from_w(normal);
+    const u32x4 ph = philox4x32_10(g.pixel, g.sample, g.site, 0u, g.k0, g.k1);
+    if (u01(ph.x) < 0.5) {
+        const int idx = (int)u_range(ph.y, 0, (S.n_lights - 1) + 1);
+        dir = shape_random(S.nodes[S.lights[idx < MAX_LIGHT_SHAPES ? idx : 0]], p, ph.z, ph.w);
+    } else {  // random_cosine_direction
+        const double r1 = u01(ph.z), r2 = u01(ph.w);
+        const double z = sqrt(1 - r2);
+        const double phi = 2 * PI_D * r1;
+        const double x = cos(phi) * sqrt(r2);
+        const double y = sin(phi) * sqrt(r2);
+        dir = onb_local(uvw, d3{x, y, z});
+    }
+    const d3 ud = unit_vector(dir);
+    const double cosine_w = dot(ud, uvw.w);
+    const double cos_pdf = (cosine_w <= 0) ? 0 : cosine_w / PI_D;
+    const double weight = 1.0 / S.n_lights;
+    double sum = 0.0;
+    for (int i = 0; i < S.n_lights; ++i) sum += weight * shape_pdf_value(S.nodes[S.lights[i]], p, dir);
+    const double pdf_val = 0.5 * sum + 0.5 * cos_pdf;
+    const double cosine_n = dot(normal, ud);
+    const double spdf = cosine_n < 0 ? 0 : cosine_n / PI_D;
+    return (1 / pdf_val) * (spdf * attenuation);
+}
+
 __device__ __forceinline__ Ray primary_ray(const CameraDev& C, int W, int H, uint32_t pixel, uint32_t sample, uint32_t k0,
                                            uint32_t k1, double& tm) {
     const int i = (int)(pixel % (uint32_t)W);
@@ -614,9 +704,17 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 const MaterialDev m = S.materials[s.mat];
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
-                const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_ISOTROPIC;
+                const bool importance = (F & F_IS) != 0;  // variants with F_IS only run with RT_RENDER_IMPORTANCE
+                const bool wants_sphere = (!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
+                                          (!importance && m.kind == RT_MAT_ISOTROPIC);
                 const d3 rs = random_in_unit_sphere(wants_sphere, g.pixel, g.sample, g.site, A.key0, A.key1);
-                if (m.kind == RT_MAT_LAMBERTIAN) {  // B2/material.h:25-36
+                if (importance && m.kind == RT_MAT_LAMBERTIAN) {  // book 3: mixture of light and cosine densities
+                    attenuation = importance_bounce(S, s.p, s.normal, texture_value<F>(S, m.tex, s), g, nd);
+                } else if (importance && m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
+                    // book 3: a light emits from its front face only and ends the path; nothing else scatters
+                    if (m.kind == RT_MAT_DIFFUSE_LIGHT && s.front_face) L_end = texture_value<F>(S, m.tex, s);
+                    done = true;
+                } else if (m.kind == RT_MAT_LAMBERTIAN) {  // B2/material.h:25-36
                     nd = s.normal + unit_vector(rs);
                     const double eps = 1e-8;
                     if ((fabs(nd.x) < eps) && (fabs(nd.y) < eps) && (fabs(nd.z) < eps)) nd = s.normal;
@@ -624,7 +722,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 } else if (m.kind == RT_MAT_METAL) {  // B2/material.h:46-53
                     const d3 reflected = reflect(unit_vector(r.d), s.normal);
                     nd = reflected + m.param * rs;
-                    if (!(dot(nd, s.normal) > 0)) done = true;  // no scatter, nothing emitted
+                    // books 1/2: no scatter below the surface, nothing emitted; book 3 follows the ray regardless
+                    if (!importance && !(dot(nd, s.normal) > 0)) done = true;
                 } else if (m.kind == RT_MAT_DIELECTRIC) {  // B2/material.h:64-83
                     attenuation = d3{1.0, 1.0, 1.0};
                     const double refraction_ratio = s.front_face ? (1.0 / m.param) : m.param;
@@ -711,6 +810,7 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
 constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
 constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
 constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE;  // textured spheres and lights
+constexpr int V_IS = F_RECT | F_XF | F_IS;                   // book 3's Cornell box, light sampled by importance
 typedef void (*scene_kernel_t)(const SceneRenderArgs);
 struct SceneVariant {
     int features;
@@ -721,15 +821,22 @@ static const SceneVariant g_variants[] = {
     {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
     {V_C, k_render_scene<V_C, 2>},
     {F_ALL, k_render_scene<F_ALL, RT_SCENE_MIN_WAVES>},
+    {V_IS, k_render_scene<V_IS, 2>},
+    {F_ALL | F_IS, k_render_scene<F_ALL | F_IS, 2>},
 };
-static const SceneVariant& variant_for(int features) {
-    for (const SceneVariant& v : g_variants)
+static const SceneVariant& variant_for(int features, bool importance) {
+    features = (features & F_ALL) | (importance ? F_IS : 0);
+    const SceneVariant* last = nullptr;
+    for (const SceneVariant& v : g_variants) {
+        if (((v.features & F_IS) != 0) != importance) continue;
+        last = &v;
         if ((features & ~v.features) == 0) return v;
-    return g_variants[sizeof(g_variants) / sizeof(g_variants[0]) - 1];
+    }
+    return *last;
 }
 
 hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(variant_for(args.scene.features).kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(variant_for(args.scene.features, args.importance != 0).kernel, dim3((unsigned)blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -761,7 +868,8 @@ int scene_feature_bit_for_node(int kind) {
     case RT_NODE_YZ_RECT:
     case RT_NODE_BOX: return F_RECT;
     case RT_NODE_TRANSLATE:
-    case RT_NODE_ROTATE_Y: return F_XF;
+    case RT_NODE_ROTATE_Y:
+    case RT_NODE_FLIP_FACE: return F_XF;
     case RT_NODE_MEDIUM: return F_MEDIUM;
     default: return 0;
     }
@@ -771,9 +879,9 @@ int scene_feature_bit_for_texture(int kind) {
 }
 int scene_feature_bit_for_material(int kind) { return kind == RT_MAT_ISOTROPIC ? F_MEDIUM : 0; }
 
-int render_scene_blocks_per_cu(int features) {
+int render_scene_blocks_per_cu(int features, bool importance) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, variant_for(features).kernel, 256, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, variant_for(features, importance).kernel, 256, 0) != hipSuccess || n < 1) n = 1;
     return n;
 }
 

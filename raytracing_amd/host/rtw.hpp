@@ -398,6 +398,16 @@ struct rotate_y : hittable {
     }
 };
 
+// flip_face of "The Rest Of Your Life" (public book text; the reference repository has no book-3 code)
+struct flip_face : hittable {
+    shared_ptr<hittable> ptr;
+    explicit flip_face(shared_ptr<hittable> p) : ptr(std::move(p)) {}
+    int emit(flattener& f) const override;
+    bool bounding_box(double time0, double time1, aabb& output_box) const override {
+        return ptr->bounding_box(time0, time1, output_box);
+    }
+};
+
 struct constant_medium : hittable {
     shared_ptr<hittable> boundary;
     shared_ptr<material> phase_function;
@@ -473,6 +483,7 @@ public:
     std::vector<std::vector<uint8_t>> image_bytes;
 
     int material_index(const shared_ptr<material>& m) {
+        if (!m) return -1;  // the shapes of a light list carry no material
         auto it = mats_seen_.find(m.get());
         if (it != mats_seen_.end()) return it->second;
         const rt_material d = m->describe(*this);
@@ -513,8 +524,11 @@ public:
         children.insert(children.end(), kids.begin(), kids.end());
         return self;
     }
-    // world must be the root list.  sky_mode / background as in rt_scene_desc.
-    rt_scene_desc flatten(const hittable_list& world, int sky_mode = RT_SKY_GRADIENT, color background = color(0, 0, 0)) {
+    // world must be the root list.  sky_mode / background as in rt_scene_desc.  `lights` = the shapes light is
+    // sampled towards under RT_RENDER_IMPORTANCE (book 3's lights argument), written after the world as a list
+    // node of their own.
+    rt_scene_desc flatten(const hittable_list& world, int sky_mode = RT_SKY_GRADIENT, color background = color(0, 0, 0),
+                          const hittable_list* lights = nullptr) {
         nodes.clear();
         children.clear();
         materials.clear();
@@ -525,6 +539,7 @@ public:
         mats_seen_.clear();
         tex_seen_.clear();
         const int root = world.emit(*this);
+        const int lights_node = lights ? lights->emit(*this) : -1;
         for (size_t i = 0; i < images.size(); ++i) images[i].rgb = image_bytes[i].data();
         rt_scene_desc d;
         std::memset(&d, 0, sizeof(d));
@@ -543,6 +558,7 @@ public:
         d.perlins = perlins.data();
         d.images = images.data();
         d.sky_mode = sky_mode;
+        d.lights_plus1 = lights_node + 1;
         for (int i = 0; i < 3; ++i) d.background[i] = background[i];
         return d;
     }
@@ -640,6 +656,12 @@ inline int bvh_node::emit(flattener& f) const {
 inline int translate::emit(flattener& f) const {
     const int i = f.push_node(RT_NODE_TRANSLATE, -1);
     for (int c = 0; c < 3; ++c) f.nodes[i].p[c] = offset[c];
+    const int k = ptr->emit(f);
+    f.nodes[i].child0 = k;
+    return i;
+}
+inline int flip_face::emit(flattener& f) const {
+    const int i = f.push_node(RT_NODE_FLIP_FACE, -1);
     const int k = ptr->emit(f);
     f.nodes[i].child0 = k;
     return i;
