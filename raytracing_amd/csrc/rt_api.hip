@@ -629,10 +629,11 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const int item_cap = item_cap_for(p);
-    const ItemPlan plan = make_item_plan(p->sample_count, item_cap);
-    const int64_t items = (int64_t)plan.levels * p->width * p->height;
-    if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
+    const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
     const bool spheres = ctx->path == PATH_SPHERE_LIST;
+    const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, spheres);
+    const int64_t items = (int64_t)item_count(plan, npix);
+    if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
     const bool importance = (p->flags & RT_RENDER_IMPORTANCE) != 0;
     if (importance && (spheres || !ctx->graph_can_importance))
         return fail(ctx, RT_ERR_UNSUPPORTED_SCENE,

@@ -43,6 +43,8 @@ enum : int {
     F_IMAGE = 64,    // image textures
     F_ALL = 127,
     F_IS = 128,      // ray_color of book 3: light sampled by importance (RT_RENDER_IMPORTANCE); not part of F_ALL
+    F_FLIP = 256,    // flip_face wrappers (book 3); not part of F_ALL, implies the instance machinery (F_XF)
+    F_EVERY = F_ALL | F_FLIP,
 };
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
 
@@ -53,8 +55,8 @@ struct Ray {
 __device__ __forceinline__ double comp(d3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // Ray handed to the child of a translate / rotate_y node (B2/hittable.h:44, 114-123).
+// (A flip_face node hands its ray on unchanged: callers compiled with F_FLIP check for it before calling.)
 __device__ __forceinline__ Ray xf_apply(const SceneNode& n, Ray r) {
-    if (n.kind == RT_NODE_FLIP_FACE) return r;  // flip_face hands its ray on unchanged
     if (n.kind == RT_NODE_TRANSLATE) {
         r.o = r.o - d3{n.p[0], n.p[1], n.p[2]};
         return r;
@@ -80,10 +82,14 @@ __device__ __forceinline__ Ray ray_in(const SceneDev& S, int xf, Ray world) {
     if (x >= 0) { c2 = x; x = S.parent_xf[x]; }
     if (x >= 0) { c3 = x; }
     Ray r = world;
-    if (c3 >= 0) r = xf_apply(S.nodes[c3], r);
-    if (c2 >= 0) r = xf_apply(S.nodes[c2], r);
-    if (c1 >= 0) r = xf_apply(S.nodes[c1], r);
-    if (c0 >= 0) r = xf_apply(S.nodes[c0], r);
+    const int chain[4] = {c3, c2, c1, c0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (chain[k] < 0) continue;
+        const SceneNode n = S.nodes[chain[k]];
+        if ((F & F_FLIP) != 0 && n.kind == RT_NODE_FLIP_FACE) continue;
+        r = xf_apply(n, r);
+    }
     return r;
 }
 
@@ -349,11 +355,12 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     if ((int)tag + 1 < n.b) stack[(sp++) * 64 + lane] = (uint32_t)e | ((tag + 1u) << 16);
                     stack[(sp++) * 64 + lane] = (uint32_t)S.children[n.a + (int)tag];
                 }
-            } else if ((F & F_XF) != 0 && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y || kind == RT_NODE_FLIP_FACE)) {
+            } else if ((F & F_XF) != 0 && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y ||
+                                           ((F & F_FLIP) != 0 && kind == RT_NODE_FLIP_FACE))) {
                 const bool rotates = kind == RT_NODE_ROTATE_Y;
                 stack[(sp++) * 64 + lane] = (uint32_t)e | ((rotates ? END_XF : END_XF_TRANSLATE) << 16);
                 stack[(sp++) * 64 + lane] = (uint32_t)n.a;
-                cur = xf_apply(n, cur);
+                if (!((F & F_FLIP) != 0 && kind == RT_NODE_FLIP_FACE)) cur = xf_apply(n, cur);
                 cur_xf = e;
                 if (rotates) {
                     inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
@@ -438,7 +445,7 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
     for (int x = h.xf, lvl = 0; x >= 0 && lvl < XF_DEPTH_CAP; x = S.parent_xf[x], ++lvl) {
         const SceneNode xn = S.nodes[x];
         const Ray child_ray = ray_in<F>(S, x, w);
-        if (xn.kind == RT_NODE_FLIP_FACE) {
+        if ((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE) {
             s.front_face = !s.front_face;
         } else if (xn.kind == RT_NODE_TRANSLATE) {
             s.p = s.p + d3{xn.p[0], xn.p[1], xn.p[2]};
@@ -659,7 +666,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     const CameraDev& cam = s_cam[threadIdx.x >> 6];
     const SceneDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
-    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
+    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, false);
 
     bool active = false;
     uint32_t bounce = 0;
@@ -669,11 +676,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     double tm = 0.0;
     LaneWork w{};
     WaveWork wq{};
-    const WorkQueues Q{A.item_counter, A.n_items, A.accum};
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum, nullptr};  // no accumulation cache: these kernels are short of registers
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0;
 
     for (;;) {
-        if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
+        if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
         if (!active && w.has_item) {
             r = primary_ray(cam, A.width, A.height, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, tm);
             T = d3{1, 1, 1};
@@ -795,7 +802,7 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
     const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
     const Ray r{origin + offset, llc + s * hor + t * ver - origin - offset};
     const RngCtx g{pc, 0u, 1u, 0u, 0u};
-    const Hit h = trace<F_ALL>(A.scene, r, C.time0, on, stack, lane, g);
+    const Hit h = trace<F_EVERY>(A.scene, r, C.time0, on, stack, lane, g);
     if (on) A.ids[pixel] = h.node < 0 ? -1 : A.scene.top_of[h.node];
 }
 
@@ -810,7 +817,7 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
 constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
 constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
 constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE;  // textured spheres and lights
-constexpr int V_IS = F_RECT | F_XF | F_IS;                   // book 3's Cornell box, light sampled by importance
+constexpr int V_IS = F_RECT | F_XF | F_FLIP | F_IS;          // book 3's Cornell box, light sampled by importance
 typedef void (*scene_kernel_t)(const SceneRenderArgs);
 struct SceneVariant {
     int features;
@@ -821,11 +828,12 @@ static const SceneVariant g_variants[] = {
     {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
     {V_C, k_render_scene<V_C, 2>},
     {F_ALL, k_render_scene<F_ALL, RT_SCENE_MIN_WAVES>},
+    {F_EVERY, k_render_scene<F_EVERY, RT_SCENE_MIN_WAVES>},
     {V_IS, k_render_scene<V_IS, 2>},
-    {F_ALL | F_IS, k_render_scene<F_ALL | F_IS, 2>},
+    {F_EVERY | F_IS, k_render_scene<F_EVERY | F_IS, 2>},
 };
 static const SceneVariant& variant_for(int features, bool importance) {
-    features = (features & F_ALL) | (importance ? F_IS : 0);
+    features = (features & F_EVERY) | (importance ? F_IS : 0);
     const SceneVariant* last = nullptr;
     for (const SceneVariant& v : g_variants) {
         if (((v.features & F_IS) != 0) != importance) continue;
@@ -868,8 +876,8 @@ int scene_feature_bit_for_node(int kind) {
     case RT_NODE_YZ_RECT:
     case RT_NODE_BOX: return F_RECT;
     case RT_NODE_TRANSLATE:
-    case RT_NODE_ROTATE_Y:
-    case RT_NODE_FLIP_FACE: return F_XF;
+    case RT_NODE_ROTATE_Y: return F_XF;
+    case RT_NODE_FLIP_FACE: return F_XF | F_FLIP;
     case RT_NODE_MEDIUM: return F_MEDIUM;
     default: return 0;
     }

@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     const CameraDev& cam = s_cam[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
-    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap);
+    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, true);
+    __shared__ AccumCache s_acc[4];
+    accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
 
     // per-lane path state
     bool active = false;
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     d3 o{0, 0, 0}, d{0, 0, 1}, T{1, 1, 1};
     LaneWork w{};
     WaveWork wq{};
-    const WorkQueues Q{A.item_counter, A.n_items, A.accum};
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6]};
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0, n_overflow = 0;
 #ifdef RT_TAIL_PROBE
     const uint64_t pr_t0 = wall_clock64();
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     pc.start();
     for (;;) {
         // ---- refill: finish items, take new ones, start the next sample
-        if (!refill_work(Q, plan, npix, A.sample_begin, lane, active, w, wq)) break;
+        if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
         if (!active && w.has_item) {
             const int i = (int)(w.pixel % (uint32_t)A.width);
             const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
@@ -424,6 +426,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
         pc.mark(SEC_SHADE);
     }
 
+    accum_cache_flush(Q, lane);
 #ifdef RT_TAIL_PROBE
     if (lane == 0 && A.probe) {
         uint64_t* w = A.probe + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));

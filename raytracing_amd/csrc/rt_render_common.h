@@ -77,12 +77,18 @@ __device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
 
 // Work items.  The samples [0, N) of a pixel are cut into `levels` runs: K runs of `cap` samples, then the
 // remaining R = N - K*cap (cap <= R < 2*cap when N >= cap) halved repeatedly: R - R/2, R/2 - R/4, ..., 1.
-// Item m is run (m / npix) of pixel (m % npix), so the queue hands out every pixel's long runs first and
-// one-sample runs last: few atomics per pixel, and a fine-grained tail at the end of the launch.
+// Items are numbered in two passes.  First the K full runs, pixel by pixel (all K runs of pixel 0, then of pixel 1,
+// ...): the 64 items of a batch belong to one or a few neighbouring pixels, so the lanes of a wave trace similar
+// rays and their sums meet in the wave's accumulation cache (below) instead of in memory.  Then the halved
+// remainders, run by run over the whole frame (every pixel's largest remainder first, one-sample runs last): the
+// queue ends in fine grains spread over all pixels, whatever single pixels cost.
 struct ItemPlan {
     int32_t cap, K, R, levels;
+    uint32_t npix;
+    uint32_t bulk_items;  // npix * K
 };
-__host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap) {
+// pixel_pass = false numbers every run frame by frame (no pixel-by-pixel pass, no use for the cache).
+__host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap, uint32_t npix, bool pixel_pass) {
     ItemPlan p;
     p.cap = cap < 1 ? 1 : cap;
     p.K = n_samples / p.cap - 1;
@@ -91,7 +97,12 @@ __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t ca
     int bits = 0;
     for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
     p.levels = p.K + bits;
+    p.npix = npix;
+    p.bulk_items = (pixel_pass && p.K >= 2) ? npix * (uint32_t)p.K : 0u;
     return p;
+}
+__host__ __device__ inline uint64_t item_count(const ItemPlan& p, uint32_t npix) {
+    return (uint64_t)npix * (uint64_t)p.levels;
 }
 // samples [first, first + count) of run `level`, relative to the first sample of the call
 __device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& first, int& count) {
@@ -104,6 +115,31 @@ __device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& firs
         count = (p.R >> g) - (p.R >> (g + 1));
     }
 }
+// item number -> pixel and samples [first, first + count)
+__device__ __forceinline__ void item_lookup(const ItemPlan& p, uint32_t item, uint32_t& pixel, int& first, int& count) {
+    int level;
+    if (item < p.bulk_items) {
+        pixel = item / (uint32_t)p.K;
+        level = (int)(item - pixel * (uint32_t)p.K);
+    } else {
+        const uint32_t t = item - p.bulk_items;
+        const uint32_t l = t / p.npix;
+        pixel = t - l * p.npix;
+        level = (p.bulk_items != 0u ? p.K : 0) + (int)l;
+    }
+    item_run(p, level, first, count);
+}
+
+// Accumulation cache of one wave (in LDS): fixed-point sums of the pixels the wave is working on.  A finished
+// item adds its sums here; a pixel's sums go to memory (three 64-bit atomics) when another pixel needs its slot
+// or when the wave ends.  With pixel-by-pixel item numbering almost all items of a pixel meet in one slot, which
+// cuts the atomics that reach memory by the number of items per pixel.
+constexpr int ACC_SLOTS = 16;
+constexpr uint32_t ACC_EMPTY = 0xFFFFFFFFu;
+struct AccumCache {
+    int64_t sum[ACC_SLOTS][3];
+    uint32_t tag[ACC_SLOTS];
+};
 
 // ---------------------------------------------------------------- work source of a persistent wave
 //
@@ -117,9 +153,66 @@ struct WorkQueues {
     uint32_t* counter;  // head of the item queue, zeroed before launch
     uint32_t n_items;
     int64_t* accum;
+    AccumCache* cache;  // this wave's accumulation cache (LDS), set up with accum_cache_init; nullptr: none, and the
+                        // plan must have been made without the pixel-by-pixel pass
 };
+
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void accum_cache_init(AccumCache* c, int lane) {
+    if (lane < ACC_SLOTS) {
+        c->tag[lane] = ACC_EMPTY;
+        c->sum[lane][0] = c->sum[lane][1] = c->sum[lane][2] = 0;
+    }
+    lds_wave_sync();
+}
+__device__ __forceinline__ void accum_slot_to_memory(const WorkQueues& Q, int slot, uint32_t pixel) {
+    atomic_add_i64(Q.accum + 3ull * pixel + 0, Q.cache->sum[slot][0]);
+    atomic_add_i64(Q.accum + 3ull * pixel + 1, Q.cache->sum[slot][1]);
+    atomic_add_i64(Q.accum + 3ull * pixel + 2, Q.cache->sum[slot][2]);
+}
+// Adds the sums of the lanes with `fl` set (their finished items) to the cache.  All 64 lanes must call it.
+__device__ __forceinline__ void accum_cache_add(const WorkQueues& Q, int lane, bool fl, uint32_t pixel, int64_t fx, int64_t fy,
+                                                int64_t fz) {
+    uint64_t todo = ballot(fl);
+    while (todo != 0ull) {  // one trip per distinct pixel among the finishing lanes
+        const int src = __builtin_ctzll(todo);
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pixel, src);
+        const int slot = (int)(p & (uint32_t)(ACC_SLOTS - 1));
+        const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.cache->tag[slot]);
+        if (tag != p) {  // wave-uniform: the slot holds another pixel (or nothing): write it back, take the slot
+            if (lane == src) {
+                if (tag != ACC_EMPTY) accum_slot_to_memory(Q, slot, tag);
+                Q.cache->sum[slot][0] = Q.cache->sum[slot][1] = Q.cache->sum[slot][2] = 0;
+                Q.cache->tag[slot] = p;
+            }
+            lds_wave_sync();
+        }
+        const bool mine = fl && pixel == p;
+        if (mine) {
+            __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[slot][0], (unsigned long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[slot][1], (unsigned long long)fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[slot][2], (unsigned long long)fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        lds_wave_sync();
+        todo &= ~ballot(mine);
+    }
+}
+// Writes every occupied slot back; the wave calls it once, after its last item.
+__device__ __forceinline__ void accum_cache_flush(const WorkQueues& Q, int lane) {
+    if (Q.cache == nullptr) return;
+    lds_wave_sync();
+    if (lane < ACC_SLOTS) {
+        const uint32_t tag = Q.cache->tag[lane];
+        if (tag != ACC_EMPTY) accum_slot_to_memory(Q, lane, tag);
+    }
+}
 struct LaneWork {
     bool has_item;
+    bool cached;  // the item's sums go through the wave's accumulation cache (items of the pixel-by-pixel pass)
     uint32_t pixel;
     int32_t s_cur, s_end;  // next sample to start / end of the run
     int64_t fx, fy, fz;    // fixed-point sums of the finished samples of the item
@@ -131,13 +224,20 @@ struct WaveWork {
 
 // One refill step for the wave; `active` = lane has a path in flight.  Returns false when the wave is done.
 // Afterwards a lane with has_item && !active must start sample s_cur.
-__device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan& plan, uint32_t npix, int32_t sample_begin,
+__device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan& plan, int32_t sample_begin,
                                             int lane, bool active, LaneWork& w, WaveWork& q) {
-    if (!active && w.has_item && w.s_cur == w.s_end) {
-        atomic_add_i64(Q.accum + 3ull * w.pixel + 0, w.fx);
-        atomic_add_i64(Q.accum + 3ull * w.pixel + 1, w.fy);
-        atomic_add_i64(Q.accum + 3ull * w.pixel + 2, w.fz);
-        w.has_item = false;
+    {
+        const bool finished = !active && w.has_item && w.s_cur == w.s_end;
+        // Items of the pixel-by-pixel pass meet their pixel's other items in the cache; the few remainder items and
+        // handed-over samples of a pixel are far apart in time and go to memory directly.
+        if (Q.cache != nullptr && ballot(finished && w.cached) != 0ull)
+            accum_cache_add(Q, lane, finished && w.cached, w.pixel, w.fx, w.fy, w.fz);
+        if (finished && !w.cached) {
+            atomic_add_i64(Q.accum + 3ull * w.pixel + 0, w.fx);
+            atomic_add_i64(Q.accum + 3ull * w.pixel + 1, w.fy);
+            atomic_add_i64(Q.accum + 3ull * w.pixel + 2, w.fz);
+        }
+        if (finished) w.has_item = false;
     }
     bool need = !active && !w.has_item;
     while (!q.dry && ballot(need) != 0ull) {
@@ -156,10 +256,9 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
         const uint32_t rank = rank_below(m);
         const uint32_t avail = q.batch_end - q.batch_next;
         if (need && rank < avail) {
-            const uint32_t item = q.batch_next + rank;
-            w.pixel = item % npix;
             int first, count;
-            item_run(plan, (int)(item / npix), first, count);
+            item_lookup(plan, q.batch_next + rank, w.pixel, first, count);
+            w.cached = q.batch_next + rank < plan.bulk_items;
             w.s_cur = sample_begin + first;
             w.s_end = w.s_cur + count;
             w.fx = w.fy = w.fz = 0;
@@ -180,6 +279,7 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
         const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)w.pixel, g);
         const int32_t smp = __builtin_amdgcn_readlane(w.s_end, g);
         if (lane == t) {
+            w.cached = false;
             w.pixel = px;
             w.s_cur = smp;
             w.s_end = smp + 1;
