@@ -31,6 +31,9 @@ struct rt_context {
     int blocks_per_cu_spheres = 0;
     int blocks_per_cu_scene = 0;
     bool graph_can_importance = false;  // the uploaded world has light shapes and no isotropic material
+    // sphere-list launches with at least this many samples per pixel use the pixel-by-pixel pass (measured
+    // crossover on config 2: slower by 0.5 ms at 32 spp, faster by 1.8 ms at 500 spp)
+    int pixel_pass_min_samples = 100;
     int blocks_override = 0;
     std::string detail;
     bool exact_only = false;     // validation: bypass the float screen
@@ -521,6 +524,7 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
         return rc;
     }
     ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu();
+    if (const char* s = std::getenv("RT_PIXEL_PASS")) ctx->pixel_pass_min_samples = std::atoi(s) != 0 ? 0 : 0x7FFFFFFF;
     if (const char* s = std::getenv("RT_BLOCKS_PER_CU")) {
         int v = std::atoi(s);
         if (v >= 1 && v <= 8) ctx->blocks_override = v;
@@ -631,7 +635,9 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     const int item_cap = item_cap_for(p);
     const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
     const bool spheres = ctx->path == PATH_SPHERE_LIST;
-    const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, spheres);
+    // the pixel-by-pixel pass pays off from about a hundred samples per pixel (RT_PIXEL_PASS=0/1 overrides)
+    bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
+    const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, pixel_pass);
     const int64_t items = (int64_t)item_count(plan, npix);
     if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
     const bool importance = (p->flags & RT_RENDER_IMPORTANCE) != 0;
@@ -672,6 +678,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;
         A.item_cap = item_cap;
+        A.pixel_pass = pixel_pass ? 1 : 0;
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);

@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     const CameraDev& cam = s_cam[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
-    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, true);
+    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, A.pixel_pass != 0);
     __shared__ AccumCache s_acc[4];
     accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
 

@@ -199,6 +199,22 @@ def test_small_frames_hand_samples_to_idle_lanes(ctx, scene_c2, monkeypatch, W, 
     assert st["samples"] == W * H * spp and st["rays"] == ost["rays"]
 
 
+@pytest.mark.parametrize("W,H,spp,force", [(40, 30, 130, None), (64, 48, 37, "1"), (21, 9, 100, None), (40, 30, 130, "0")])
+def test_pixel_pass_and_accumulation_cache(scene_c2, monkeypatch, W, H, spp, force):
+    """From 100 samples per pixel on, the full runs of a pixel are handed out together and their sums meet in a
+    per-wave LDS cache before they reach memory (RT_PIXEL_PASS forces it on or off).  Same sums, bit for bit."""
+    if force is not None:
+        monkeypatch.setenv("RT_PIXEL_PASS", force)
+    cam = lib.camera(*CAM_C2)
+    p = abi.render_params(W, H, spp, 50, seed=31, sample_begin=5)
+    with lib.Context(0) as c:
+        c.upload(scene_c2)
+        got, st = c.render(cam, p)
+    want, ost = oracle_sums(scene_c2, cam, p)
+    assert np.array_equal(got, want)
+    assert st["samples"] == W * H * spp and st["rays"] == ost["rays"]
+
+
 def test_candidate_overflow_takes_the_exact_path(ctx):
     """48 nested glass shells: every central ray has more candidates than LDS slots."""
     sph = [(0, 0, 0, 1.0 + 0.05 * k, 0) for k in range(48)]
