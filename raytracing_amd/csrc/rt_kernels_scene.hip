@@ -311,11 +311,18 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
     int cur_xf = -1;
     d3 inv{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
     double a = len2(cur.d);
-    int sp = 0;
-    if (on) stack[(sp++) * 64 + lane] = (uint32_t)S.root;
 #ifdef RT_SCENE_PROBE
     if (lane == 0) atomicAdd(&g_probe_total[14], 1ull);
 #endif
+    // The world (a list, checked at upload) is walked by the wave as a whole: all lanes enter its k-th object
+    // together and leave it together.  Each lane still meets the objects in list order with its own
+    // closest-so-far value, but the lanes of a trip are now inside the same object: a sphere or a medium of the
+    // world is tested by all lanes at once, and inside a BVH only box code and its leaves' code are live.
+    const int top_first = __builtin_amdgcn_readfirstlane(S.nodes[S.root].a);
+    const int top_count = __builtin_amdgcn_readfirstlane(S.nodes[S.root].b);
+    for (int top = 0; top < top_count; ++top) {
+    int sp = 0;
+    if (on) stack[(sp++) * 64 + lane] = (uint32_t)S.children[top_first + top];
 
     while (ballot(sp > 0) != 0ull) {
 #ifdef RT_SCENE_PROBE
@@ -383,6 +390,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                 }
             }
         }
+    }
     }
     return h;
 }
