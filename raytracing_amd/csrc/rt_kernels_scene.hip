@@ -723,17 +723,22 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 const bool wants_sphere = (!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
                                           (!importance && m.kind == RT_MAT_ISOTROPIC);
                 const d3 rs = random_in_unit_sphere(wants_sphere, g.pixel, g.sample, g.site, A.key0, A.key1);
+                // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code)
+                const bool wants_texture = m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
+                                           (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face));
+                d3 tex{0, 0, 0};
+                if (wants_texture) tex = texture_value<F>(S, m.tex, s);
                 if (importance && m.kind == RT_MAT_LAMBERTIAN) {  // book 3: mixture of light and cosine densities
-                    attenuation = importance_bounce(S, s.p, s.normal, texture_value<F>(S, m.tex, s), g, nd);
+                    attenuation = importance_bounce(S, s.p, s.normal, tex, g, nd);
                 } else if (importance && m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
                     // book 3: a light emits from its front face only and ends the path; nothing else scatters
-                    if (m.kind == RT_MAT_DIFFUSE_LIGHT && s.front_face) L_end = texture_value<F>(S, m.tex, s);
+                    if (m.kind == RT_MAT_DIFFUSE_LIGHT && s.front_face) L_end = tex;
                     done = true;
                 } else if (m.kind == RT_MAT_LAMBERTIAN) {  // B2/material.h:25-36
                     nd = s.normal + unit_vector(rs);
                     const double eps = 1e-8;
                     if ((fabs(nd.x) < eps) && (fabs(nd.y) < eps) && (fabs(nd.z) < eps)) nd = s.normal;
-                    attenuation = texture_value<F>(S, m.tex, s);
+                    attenuation = tex;
                 } else if (m.kind == RT_MAT_METAL) {  // B2/material.h:46-53
                     const d3 reflected = reflect(unit_vector(r.d), s.normal);
                     nd = reflected + m.param * rs;
@@ -753,9 +758,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                     nd = do_reflect ? reflect(unit_direction, s.normal) : refract(unit_direction, s.normal, refraction_ratio);
                 } else if ((F & F_MEDIUM) != 0 && m.kind == RT_MAT_ISOTROPIC) {  // B2/material.h:121-127
                     nd = rs;
-                    attenuation = texture_value<F>(S, m.tex, s);
+                    attenuation = tex;
                 } else {  // diffuse_light: emits, does not scatter (B2/material.h:102-110)
-                    L_end = texture_value<F>(S, m.tex, s);
+                    L_end = tex;
                     done = true;
                 }
                 if (!done) {
