@@ -85,6 +85,26 @@ def cpu_baseline(scene_path):
             "sample": sample + "; oracle/rt_oracle.c, gcc -O2, 1 thread"}
 
 
+def cpu_baseline_all_cores(processes):
+    """The reference author's own recipe for more cores ("Ray Tracing In a Weekend/README.md":2538-2542): P copies of
+    the reference renderer, each with its own seed and spp/P samples, images averaged afterwards.  Context only: P
+    processes of the unmodified reference on the same bounded sample as cpu_baseline, started together."""
+    W, H, spp = 240, 160, 32
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_b1")
+    if not os.path.exists(ref) or processes < 2:
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([ref, "render", "c2", str(W), str(H), str(spp), "50", str(1000 + k), os.path.join(tmp, f"o{k}.f64")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for k in range(processes)]
+        ok = all(p.wait() == 0 for p in procs)
+        dt = time.perf_counter() - t0
+    if not ok:
+        return None
+    return {"value": processes * W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": processes, "kind": "reference",
+            "sample": f"{processes} processes of the unmodified reference, distinct srand() seeds, {W}x{H}x{spp} each, run together"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +269,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path)
+            many = cpu_baseline_all_cores(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1))
+            if many:
+                out["cpu_baseline_all_cores"] = many
         print(json.dumps(out), flush=True)
 
     for _, c, _ in slots:
