@@ -118,6 +118,7 @@ typedef struct rt_image {
     const uint8_t* rgb;
 } rt_image;
 
+/* What a ray that leaves the world returns.  Lights (RT_MAT_DIFFUSE_LIGHT) emit under either mode. */
 enum {
     RT_SKY_GRADIENT = 0,  /* B1/RayTracing.cpp:28-30: white -> (0.5,0.7,1.0) by unit dir y    */
     RT_SKY_BACKGROUND = 1 /* B2/RayTracing.cpp:25-26: constant `background` colour             */
@@ -236,10 +237,19 @@ int rt_context_synchronize(rt_context* ctx);
 /* Validation switch: when on, kernels skip their float screening pass and test every object
  * in double.  Results must be identical either way; only the speed differs. */
 int rt_context_set_exact_only(rt_context* ctx, int on);
-/* Validation switch, read by the next rt_scene_upload: when on, a flat list of spheres is laid out and
+/* Validation switch, read by the next rt_scene_upload: when on, a world of spheres is laid out and
  * rendered as a general scene graph instead of by the dedicated sphere-list kernels.  Results must be
  * identical either way. */
 int rt_context_set_force_graph(rt_context* ctx, int on);
+/* Which kernels would render the uploaded world for this camera: RT_KERNELS_SPHERE_LIST (a flat list of
+ * spheres, B1/hittable_list.h; or a book-2 world whose only primitives are spheres and moving spheres --
+ * B2/moving_sphere.h -- under any nesting of B2/bvh.h nodes, walked as the list of its leaves while the camera's
+ * shutter interval lies inside every moving sphere's [time0, time1]), RT_KERNELS_SCENE_GRAPH (everything else),
+ * or RT_KERNELS_NONE (no world uploaded, or null arguments).  Results do not depend on the answer. */
+#define RT_KERNELS_NONE 0
+#define RT_KERNELS_SPHERE_LIST 1
+#define RT_KERNELS_SCENE_GRAPH 2
+int rt_context_kernels_for(const rt_context* ctx, const rt_camera_desc* cam);
 /* Statistics of everything rendered since the last call of this function (synchronises). */
 int rt_context_take_stats(rt_context* ctx, rt_stats* out);
 

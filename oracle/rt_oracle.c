@@ -494,7 +494,11 @@ static v3 ray_color(const rt_scene_desc* s, orc_rng* g, ray_t r, int depth, int 
     int n = 0;
     v3 L_end = V(0, 0, 0);
     v3 T = V(1, 1, 1), L = V(0, 0, 0);
+    /* the sky mode only selects what a miss returns (book 1's gradient or book 2's background); lights emit under
+     * either.  A world without lights (every book-1 world) skips the "+ emitted" of B2/RayTracing.cpp:35, which
+     * would add +0.0 and could turn a -0.0 of book 1's product chain into +0.0 */
     int emissive_scene = s->sky_mode == RT_SKY_BACKGROUND;
+    for (int k = 0; k < s->n_materials && !emissive_scene; ++k) emissive_scene = s->materials[k].kind == RT_MAT_DIFFUSE_LIGHT;
     for (uint32_t bounce = 0;; ++bounce) {
         if (depth <= 0) { L_end = V(0, 0, 0); break; }
         hit_record rec;

@@ -26,6 +26,7 @@ RT_ERR_LIMIT = 7
 (RT_NODE_SPHERE, RT_NODE_MOVING_SPHERE, RT_NODE_XY_RECT, RT_NODE_XZ_RECT, RT_NODE_YZ_RECT, RT_NODE_BOX,
  RT_NODE_LIST, RT_NODE_BVH, RT_NODE_TRANSLATE, RT_NODE_ROTATE_Y, RT_NODE_MEDIUM, RT_NODE_FLIP_FACE) = range(1, 13)
 RT_RENDER_EXACT_ONLY, RT_RENDER_IMPORTANCE = 1, 2
+RT_KERNELS_NONE, RT_KERNELS_SPHERE_LIST, RT_KERNELS_SCENE_GRAPH = 0, 1, 2
 (RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT_ISOTROPIC) = range(1, 6)
 (RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE) = range(1, 5)
 RT_SKY_GRADIENT, RT_SKY_BACKGROUND = 0, 1

@@ -29,6 +29,7 @@ struct rt_context {
     bool own_stream = false;
     int num_cus = 0;
     int blocks_per_cu_spheres = 0;
+    int blocks_per_cu_spheres_timed = 0;
     int blocks_per_cu_scene = 0;
     bool graph_can_importance = false;  // the uploaded world has light shapes and no isotropic material
     // sphere-list launches with at least this many samples per pixel use the pixel-by-pixel pass (measured
@@ -40,6 +41,12 @@ struct rt_context {
     bool force_graph = false;    // validation: lay every scene out as a scene graph
 
     ScenePath path = PATH_NONE;
+    // A book-2 world of spheres is laid out both ways: as a sphere list (spheres_timed) and as its graph.  The list's
+    // screening image bounds every moving sphere over [sweep_lo, sweep_hi]; a camera whose shutter interval leaves
+    // that range is rendered from the graph.
+    bool spheres_timed = false;
+    double sweep_lo = 0.0, sweep_hi = 0.0;
+    int sphere_set_max = 2048;  // above this many spheres the BVH walk of the graph kernels wins (RT_SPHERE_SET_MAX)
     SphereListDev spheres{};
     SceneDev graph{};
     std::vector<void*> scene_allocs;  // device memory owned by the current scene
@@ -246,6 +253,100 @@ static bool is_book1_sphere_list(const rt_scene_desc* sc) {
     return true;
 }
 
+// Leaves of a world whose only primitives are spheres and moving spheres, nested in lists and BVH nodes in any way,
+// with materials the sphere kernels shade (lambertian over solid / checker textures, metal, dielectric).  A closest
+// hit does not depend on the order of the tests, so such a world can be rendered as the list of its leaves --
+// provided no BVH node culls a leaf the list would reach: every node's box must enclose the boxes of the leaves below
+// it, a moving sphere's taken over its own [time0, time1] as B2/moving_sphere.h:80-89 does.  (bvh_node's constructor,
+// B2/bvh.h:50-95, builds exactly such boxes when it is given those times.)
+// `prims` receives the node ids in depth-first order, `tops` the index of the top-level object holding each.
+struct SphereSetWalk {
+    const rt_scene_desc* sc;
+    int max_spheres;
+    std::vector<int>& prims;
+    std::vector<int>& tops;
+    struct Box {
+        double lo[3], hi[3];
+    };
+    static Box join(const Box& a, const Box& b) {  // surrounding_box, B2/aabb.h:44-54
+        Box r;
+        for (int k = 0; k < 3; ++k) {
+            r.lo[k] = std::fmin(a.lo[k], b.lo[k]);
+            r.hi[k] = std::fmax(a.hi[k], b.hi[k]);
+        }
+        return r;
+    }
+    static Box around(const double c[3], double radius) {  // B2/sphere.h:53-58
+        Box r;
+        for (int k = 0; k < 3; ++k) {
+            r.lo[k] = c[k] - radius;
+            r.hi[k] = c[k] + radius;
+        }
+        return r;
+    }
+    bool texture_fits(int t, int depth) const {
+        const rt_texture& tx = sc->textures[t];
+        if (tx.kind == RT_TEX_SOLID) return true;
+        return tx.kind == RT_TEX_CHECKER && depth < 3 && texture_fits(tx.a, depth + 1) && texture_fits(tx.b, depth + 1);
+    }
+    bool walk(int idx, int top, Box& box) {
+        const rt_node& n = sc->nodes[idx];
+        if (n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_MOVING_SPHERE) {
+            const rt_material& m = sc->materials[n.material];
+            if (m.kind == RT_MAT_LAMBERTIAN) {
+                if (!texture_fits(m.texture, 0)) return false;
+            } else if (m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
+                return false;
+            }
+            if ((int)prims.size() >= max_spheres) return false;
+            if (n.kind == RT_NODE_SPHERE) {
+                box = around(n.p, n.p[3]);
+            } else {  // p = centre0, centre1, time0, time1, radius
+                const double time0 = n.p[6], time1 = n.p[7];
+                if (!(time0 < time1)) return false;
+                double at0[3], at1[3];
+                for (int k = 0; k < 3; ++k) {  // moving_sphere::center at both ends, B2/moving_sphere.h:27-29
+                    at0[k] = n.p[k] + ((time0 - time0) / (time1 - time0)) * (n.p[3 + k] - n.p[k]);
+                    at1[k] = n.p[k] + ((time1 - time0) / (time1 - time0)) * (n.p[3 + k] - n.p[k]);
+                }
+                box = join(around(at0, n.p[8]), around(at1, n.p[8]));
+            }
+            prims.push_back(idx);
+            tops.push_back(top);
+            return true;
+        }
+        if (n.kind == RT_NODE_BVH) {
+            Box l, r;
+            if (!walk(n.child0, top, l) || !walk(n.child1, top, r)) return false;
+            box = join(l, r);
+            for (int k = 0; k < 3; ++k)
+                if (!(n.p[k] <= box.lo[k] && n.p[3 + k] >= box.hi[k])) return false;  // this node could cull a leaf
+            for (int k = 0; k < 3; ++k) {
+                box.lo[k] = n.p[k];
+                box.hi[k] = n.p[3 + k];
+            }
+            return true;
+        }
+        if (n.kind == RT_NODE_LIST) {
+            bool first = true;
+            for (int i = 0; i < n.child1; ++i) {
+                Box c;
+                if (!walk(sc->children[n.child0 + i], idx == sc->root ? i : top, c)) return false;
+                box = first ? c : join(box, c);
+                first = false;
+            }
+            if (first) box = Box{{0, 0, 0}, {0, 0, 0}};
+            return true;
+        }
+        return false;
+    }
+};
+static bool collect_sphere_set(const rt_scene_desc* sc, int max_spheres, std::vector<int>& prims, std::vector<int>& tops) {
+    SphereSetWalk w{sc, max_spheres, prims, tops};
+    SphereSetWalk::Box box;
+    return w.walk(sc->root, -1, box);
+}
+
 static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
     std::vector<MaterialDev> mats((size_t)sc->n_materials);
     for (int i = 0; i < sc->n_materials; ++i) {
@@ -267,13 +368,18 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
     return mats;
 }
 
-static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
-    const rt_node& root = sc->nodes[sc->root];
-    const int n = root.child1;
+// Lays out the spheres `prims` (node ids, in list order) for the sphere kernels.  tops == nullptr: a book-1 list.
+// Otherwise the book-2 layout: motion records, textures, and a screening image in which a moving sphere is
+// replaced by a sphere bounding its sweep over its own [time0, time1].
+static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims,
+                              const std::vector<int>* tops) {
+    const int n = (int)prims.size();
+    const bool timed = tops != nullptr;
     const int n_pairs = (n + 1) / 2;
     const int n_chunks = std::max(1, (n_pairs + 255) / 256);
     std::vector<SpherePair> screen((size_t)n_chunks * 256);  // whole chunks: the sparse walk reads 4 pairs per lane
     std::vector<SphereExact> exact((size_t)std::max(1, n));
+    std::vector<SphereMotion> motion(timed ? (size_t)std::max(1, n) : 0);
     std::vector<int32_t> material_of((size_t)std::max(1, n));
     for (auto& s : screen) {  // padding never yields a candidate: q = -huge
         for (int h = 0; h < 2; ++h) {
@@ -281,10 +387,25 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
             s.k[h] = 3.0e38f;
         }
     }
+    double sweep_lo = -INFINITY, sweep_hi = INFINITY;
     for (int i = 0; i < n; ++i) {
-        const rt_node& nd = sc->nodes[sc->children[root.child0 + i]];
-        const double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
+        const rt_node& nd = sc->nodes[prims[(size_t)i]];
+        double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
         exact[i] = SphereExact{cx, cy, cz, r};
+        if (timed) motion[i] = SphereMotion{cx, cy, cz, 0.0, 1.0, 0};
+        if (nd.kind == RT_NODE_MOVING_SPHERE) {  // p = centre0, centre1, time0, time1, radius
+            const double dx = nd.p[3] - cx, dy = nd.p[4] - cy, dz = nd.p[5] - cz;
+            exact[i].radius = nd.p[8];
+            motion[i] = SphereMotion{nd.p[3], nd.p[4], nd.p[5], nd.p[6], nd.p[7], 1};
+            sweep_lo = std::max(sweep_lo, nd.p[6]);
+            sweep_hi = std::min(sweep_hi, nd.p[7]);
+            // every centre(t), t in [time0, time1], lies on the segment centre0..centre1 (up to a few ulps): bound it by
+            // the sphere around the midpoint, widened by a relative 1e-6 -- far more than those ulps
+            cx += 0.5 * dx;
+            cy += 0.5 * dy;
+            cz += 0.5 * dz;
+            r = (std::fabs(nd.p[8]) + 0.5 * std::sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-6) + 1e-300;
+        }
         material_of[i] = nd.material;
         const double cc = cx * cx + cy * cy + cz * cz, rr = r * r;
         const double k = cc - rr - 0x1p-18 * (cc + rr);
@@ -297,7 +418,14 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
         sp.cz[i & 1] = (float)cz;
         sp.k[i & 1] = kf;
     }
-    const std::vector<MaterialDev> mats = device_materials(sc);
+    std::vector<MaterialDev> mats = device_materials(sc);
+    // the sphere kernels read a solid albedo from the material itself; tex stays only where a checker must be evaluated
+    for (int i = 0; i < sc->n_materials; ++i) {
+        const rt_material& m = sc->materials[i];
+        const bool checker = timed && m.kind == RT_MAT_LAMBERTIAN && m.texture >= 0 && m.texture < sc->n_textures &&
+                             sc->textures[m.texture].kind == RT_TEX_CHECKER;
+        if (!checker) mats[(size_t)i].tex = -1;
+    }
 
     SphereListDev& S = ctx->spheres;
     S = SphereListDev{};
@@ -306,12 +434,21 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc) {
     if ((rc = to_device(ctx, exact, &S.exact)) != RT_OK) return rc;
     if ((rc = to_device(ctx, material_of, &S.material_of)) != RT_OK) return rc;
     if ((rc = to_device(ctx, mats, &S.materials)) != RT_OK) return rc;
+    if (timed) {
+        std::vector<int32_t> top_of(tops->begin(), tops->end());
+        if ((rc = to_device(ctx, motion, &S.motion)) != RT_OK) return rc;
+        if ((rc = to_device(ctx, top_of, &S.top_of)) != RT_OK) return rc;
+        S.textures = ctx->graph.textures;  // uploaded with the graph of the same world
+    }
     S.n = n;
     S.n_full_groups = n / SCREEN_GROUP;
     S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
     S.n_chunks = n_chunks;
     S.sky_mode = sc->sky_mode;
     for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
+    ctx->spheres_timed = timed;
+    ctx->sweep_lo = sweep_lo;
+    ctx->sweep_hi = sweep_hi;
     ctx->path = PATH_SPHERE_LIST;
     return RT_OK;
 }
@@ -523,7 +660,9 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
         rt_context_destroy(ctx);
         return rc;
     }
-    ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu();
+    ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu(false);
+    ctx->blocks_per_cu_spheres_timed = render_spheres_blocks_per_cu(true);
+    if (const char* s = std::getenv("RT_SPHERE_SET_MAX")) ctx->sphere_set_max = std::min(65535, std::max(0, std::atoi(s)));
     if (const char* s = std::getenv("RT_PIXEL_PASS")) ctx->pixel_pass_min_samples = std::atoi(s) != 0 ? 0 : 0x7FFFFFFF;
     if (const char* s = std::getenv("RT_BLOCKS_PER_CU")) {
         int v = std::atoi(s);
@@ -584,8 +723,19 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    int rc = (!ctx->force_graph && sc->lights_plus1 == 0 && is_book1_sphere_list(sc)) ? upload_sphere_list(ctx, sc)
-                                                                                        : upload_graph(ctx, sc, chk);
+    ctx->spheres_timed = false;
+    int rc;
+    std::vector<int> prims, tops;
+    const bool list_kernels = !ctx->force_graph && sc->lights_plus1 == 0;
+    if (list_kernels && is_book1_sphere_list(sc)) {
+        const rt_node& root = sc->nodes[sc->root];
+        prims.assign(sc->children + root.child0, sc->children + root.child0 + root.child1);
+        rc = upload_sphere_list(ctx, sc, prims, nullptr);
+    } else {
+        rc = upload_graph(ctx, sc, chk);
+        if (rc == RT_OK && list_kernels && collect_sphere_set(sc, ctx->sphere_set_max, prims, tops))
+            rc = upload_sphere_list(ctx, sc, prims, &tops);
+    }
     if (rc != RT_OK) free_scene(ctx);
     return rc;
 }
@@ -602,6 +752,14 @@ static void fill_camera(CameraDev& C, const rt_camera_desc* cam) {
     C.lens_radius = cam->lens_radius;
     C.time0 = cam->time0;
     C.time1 = cam->time1;
+}
+
+// Whether the sphere kernels render this camera: always for a book-1 list; for a book-2 sphere world only while
+// the times the camera gives its rays stay inside the interval the moving spheres were bounded over.
+static bool use_sphere_kernels(const rt_context* ctx, double t_first, double t_last) {
+    if (ctx->path != PATH_SPHERE_LIST) return false;
+    if (!ctx->spheres_timed) return true;
+    return std::min(t_first, t_last) >= ctx->sweep_lo && std::max(t_first, t_last) <= ctx->sweep_hi;
 }
 
 static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p) {
@@ -634,7 +792,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
 
     const int item_cap = item_cap_for(p);
     const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
-    const bool spheres = ctx->path == PATH_SPHERE_LIST;
+    const bool spheres = use_sphere_kernels(ctx, cam->time0, cam->time1);
     // the pixel-by-pixel pass pays off from about a hundred samples per pixel (RT_PIXEL_PASS=0/1 overrides)
     bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
     const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, pixel_pass);
@@ -644,7 +802,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (importance && (spheres || !ctx->graph_can_importance))
         return fail(ctx, RT_ERR_UNSUPPORTED_SCENE,
                     "RT_RENDER_IMPORTANCE needs a world uploaded with light shapes (lights_plus1) and without isotropic materials");
-    int per_cu = spheres ? ctx->blocks_per_cu_spheres
+    int per_cu = spheres ? (ctx->spheres_timed ? ctx->blocks_per_cu_spheres_timed : ctx->blocks_per_cu_spheres)
                          : (importance ? render_scene_blocks_per_cu(ctx->graph.features, true) : ctx->blocks_per_cu_scene);
     if (ctx->blocks_override) per_cu = ctx->blocks_override;
     int blocks = ctx->num_cus * per_cu;
@@ -695,7 +853,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
             g_probe = d_probe;
         }
 #endif
-        HIP_TRY(ctx, launch_render_spheres(A, blocks, ctx->stream));
+        HIP_TRY(ctx, launch_render_spheres(A, ctx->spheres_timed, blocks, ctx->stream));
     } else {
         SceneRenderArgs A{};
         A.scene = ctx->graph;
@@ -739,6 +897,11 @@ int rt_context_set_force_graph(rt_context* ctx, int on) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     ctx->force_graph = on != 0;
     return RT_OK;
+}
+
+int rt_context_kernels_for(const rt_context* ctx, const rt_camera_desc* cam) {
+    if (!ctx || !cam || ctx->path == PATH_NONE) return RT_KERNELS_NONE;
+    return use_sphere_kernels(ctx, cam->time0, cam->time1) ? RT_KERNELS_SPHERE_LIST : RT_KERNELS_SCENE_GRAPH;
 }
 
 int rt_context_take_stats(rt_context* ctx, rt_stats* out) {
@@ -830,7 +993,7 @@ int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int heig
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ids, elems * sizeof(int32_t)));
         ctx->ids_elems = elems;
     }
-    if (ctx->path == PATH_SPHERE_LIST) {
+    if (use_sphere_kernels(ctx, cam->time0, cam->time0)) {
         FirstHitArgs A{};
         A.scene = ctx->spheres;
         fill_camera(A.cam, cam);
@@ -838,7 +1001,7 @@ int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int heig
         A.height = height;
         A.exact_only = ctx->exact_only ? 1 : 0;
         A.ids = ctx->d_ids;
-        HIP_TRY(ctx, launch_first_hit_spheres(A, ctx->stream));
+        HIP_TRY(ctx, launch_first_hit_spheres(A, ctx->spheres_timed, ctx->stream));
     } else {
         SceneFirstHitArgs A{};
         A.scene = ctx->graph;

@@ -23,6 +23,15 @@ struct SpherePair {
 struct SphereExact {
     double cx, cy, cz, radius;
 };
+// Worlds of book 2 that hold nothing but spheres (static or moving, under any nesting of BVH nodes) run on the same
+// kernels: every sphere also has a SphereMotion record, and the screening image holds, for a moving sphere, the
+// sphere that bounds its sweep over [time0, time1].
+struct TextureDev;
+struct SphereMotion {
+    double c1x, c1y, c1z;  // centre at time1 (B2/moving_sphere.h:13-16); the SphereExact centre is the one at time0
+    double time0, time1;
+    int64_t moving;        // 0: static sphere, the other members are unused
+};
 struct MaterialDev {
     int32_t kind;  // RT_MAT_*
     int32_t tex;   // texture index of lambertian / diffuse_light / isotropic (general scenes), else -1
@@ -44,6 +53,10 @@ struct SphereListDev {
     const MaterialDev* materials;
     int32_t sky_mode;
     double background[3];
+    // book-2 sphere worlds only (null / 0 for a book-1 list)
+    const SphereMotion* motion;
+    const TextureDev* textures;        // solid and checker textures of the lambertian materials
+    const int32_t* top_of;              // per sphere: index within the root list of the top-level object holding it
 };
 
 struct CameraDev {
@@ -155,9 +168,10 @@ int scene_feature_bit_for_texture(int texture_kind);
 int scene_feature_bit_for_material(int material_kind);
 
 // Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.
-hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream);
-hipError_t launch_first_hit_spheres(const FirstHitArgs& args, hipStream_t stream);
+// `timed` selects the variant for book-2 sphere worlds (shutter time, moving spheres, checker textures).
+hipError_t launch_render_spheres(const RenderArgs& args, bool timed, int blocks, hipStream_t stream);
+hipError_t launch_first_hit_spheres(const FirstHitArgs& args, bool timed, hipStream_t stream);
 // Resident 256-thread workgroups per CU of the render kernel, as the runtime reports it.
-int render_spheres_blocks_per_cu();
+int render_spheres_blocks_per_cu(bool timed);
 
 }  // namespace rtd

@@ -1,4 +1,9 @@
-// gfx950 kernels for worlds that are a flat list of spheres (book 1: configs 1 and 2).
+// gfx950 kernels for worlds that are a flat list of spheres (book 1: configs 1 and 2), and, as the TIMED variant,
+// for worlds of book 2 whose only primitives are spheres and moving spheres, however they are nested in BVH nodes
+// (config 3): a closest hit does not depend on the order the objects are tested in (B2/bvh.h:97-106 and
+// B1/hittable_list.h:26-39 both keep the smallest t in [t_min, closest so far]), so the tree is walked as the list
+// of its leaves.  The TIMED variant adds B2/camera.h:44 (shutter time), B2/moving_sphere.h:27-29 and 49-77 (centre at
+// the ray's time) and B2/texture.h:37-56 (checker texture).
 //
 // Replaces, for every pixel and sample, the reference's render loop body
 //   B1/RayTracing.cpp:119-124  jitter -> camera::get_ray -> ray_color
@@ -154,9 +159,21 @@ struct Hit {
 // sphere::hit up to the accepted root, B1/sphere.h:24-41, inside the closest-so-far loop of
 // hittable_list::hit, B1/hittable_list.h:31-37.  Comparisons keep the reference's form so
 // that NaNs fall the same way.
-__device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d3 d, double a, double t_min, Hit& h) {
+// Centre of sphere j at time tm: moving_sphere::center, B2/moving_sphere.h:27-29.
+template <bool TIMED>
+__device__ __forceinline__ d3 center_at(const SphereListDev& S, int j, const SphereExact& e, double tm) {
+    d3 center{e.cx, e.cy, e.cz};
+    if constexpr (TIMED) {
+        const SphereMotion mv = S.motion[j];
+        if (mv.moving != 0) center = center + ((tm - mv.time0) / (mv.time1 - mv.time0)) * (d3{mv.c1x, mv.c1y, mv.c1z} - center);
+    }
+    return center;
+}
+
+template <bool TIMED>
+__device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d3 d, double a, double tm, double t_min, Hit& h) {
     const SphereExact e = S.exact[j];
-    const d3 oc = o - d3{e.cx, e.cy, e.cz};
+    const d3 oc = o - center_at<TIMED>(S, j, e, tm);
     const double half_b = dot(oc, d);
     const double c = len2(oc) - e.radius * e.radius;
     const double discriminant = half_b * half_b - a * c;
@@ -174,7 +191,8 @@ __device__ __forceinline__ void exact_one(const SphereListDev& S, int j, d3 o, d
 // Closest hit of one ray per lane against the whole list.  Must be called by all 64 lanes
 // of the wave (wave-level loops); lanes with on == false take no part in the result.
 // `list` = this wave's CAND_CAP*64 uint16 slots in LDS.
-__device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, bool on, bool exact_only,
+template <bool TIMED>
+__device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, double tm, bool on, bool exact_only,
                                            uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
                                            ProbeClock& pc) {
     const double a = len2(d);
@@ -183,7 +201,7 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
 
     if (exact_only) {
         if (on) {
-            for (int j = 0; j < S.n; ++j) exact_one(S, j, o, d, a, t_min, h);
+            for (int j = 0; j < S.n; ++j) exact_one<TIMED>(S, j, o, d, a, tm, t_min, h);
         }
         return h;
     }
@@ -265,12 +283,12 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
     const bool overflow = cnt > (uint32_t)CAND_CAP;
     const uint32_t my_n = overflow ? 0u : cnt;
     for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
-        if (i < my_n) exact_one(S, (int)list[i * 64 + lane], o, d, a, t_min, h);
+        if (i < my_n) exact_one<TIMED>(S, (int)list[i * 64 + lane], o, d, a, tm, t_min, h);
     }
     if (ballot(overflow) != 0ull) {
         if (overflow) {  // more candidates than slots: test the whole list in double
             ++overflow_count;
-            for (int j = 0; j < S.n; ++j) exact_one(S, j, o, d, a, t_min, h);
+            for (int j = 0; j < S.n; ++j) exact_one<TIMED>(S, j, o, d, a, tm, t_min, h);
         }
     }
     pc.mark(SEC_EXACT);
@@ -281,7 +299,23 @@ __device__ __forceinline__ Hit closest_hit(const SphereListDev& S, d3 o, d3 d, b
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 4
 #endif
-__global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A) {
+#ifndef RT_MIN_WAVES_TIMED
+#define RT_MIN_WAVES_TIMED 4
+#endif
+// texture::value of a lambertian's albedo for the textures a sphere world may use: solid_color and checker_texture
+// (B2/texture.h:23-25, 46-52), checkers nested at most three deep.
+__device__ __forceinline__ d3 sphere_world_texture(const SphereListDev& S, int ti, d3 p) {
+    for (int level = 0; level < 4; ++level) {
+        const TextureDev t = S.textures[ti];
+        if (t.kind != RT_TEX_CHECKER) return d3{t.p[0], t.p[1], t.p[2]};
+        const double sines = sin(10 * p.x) * sin(10 * p.y) * sin(10 * p.z);
+        ti = sines < 0 ? t.b : t.a;
+    }
+    return d3{0, 0, 0};
+}
+
+template <bool TIMED>
+__global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A) {
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
     __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
@@ -310,6 +344,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
     uint32_t bounce = 0;
     int depth_left = 0;
     d3 o{0, 0, 0}, d{0, 0, 1}, T{1, 1, 1};
+    double tm = 0.0;  // ray::time(), the same for every segment of a path (TIMED only)
     LaneWork w{};
     WaveWork wq{};
     const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6]};
@@ -328,6 +363,13 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             const int i = (int)(w.pixel % (uint32_t)A.width);
             const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
             camera_ray(cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, o, d);
+            if constexpr (TIMED) {
+                tm = cam.time0;
+                if (cam.time0 != cam.time1) {  // B2/camera.h:44; with equal times the draw would not change the value
+                    const u32x4 tw = philox4x32_10(w.pixel, (uint32_t)w.s_cur, 0u, TRY_TIME, A.key0, A.key1);
+                    tm = u_range(tw.x, cam.time0, cam.time1);
+                }
+            }
             T = d3{1, 1, 1};
             depth_left = A.max_depth;
             bounce = 0;
@@ -349,7 +391,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             }
         }
 #endif
-        const Hit h = closest_hit(S, o, d, on, A.exact_only != 0, list, rows, lane, n_overflow, pc);
+        const Hit h = closest_hit<TIMED>(S, o, d, tm, on, A.exact_only != 0, list, rows, lane, n_overflow, pc);
 
         // ---- shade
         if (on) {
@@ -381,10 +423,13 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
             } else {
                 // rest of sphere::hit, B1/sphere.h:43-47
                 const d3 p = o + h.t * d;
-                const d3 outward_normal = div_by(p - d3{e.cx, e.cy, e.cz}, e.radius);
+                const d3 outward_normal = div_by(p - center_at<TIMED>(S, h.id, e, tm), e.radius);
                 const bool front_face = dot(d, outward_normal) < 0;
                 const d3 normal = front_face ? outward_normal : -outward_normal;
                 d3 attenuation{m.ax, m.ay, m.az};
+                if constexpr (TIMED) {  // m.tex >= 0 only for a lambertian whose albedo is a checker texture
+                    if (m.tex >= 0) attenuation = sphere_world_texture(S, m.tex, p);
+                }
                 d3 nd{0, 0, 0};
                 const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL;
                 const d3 rs = random_in_unit_sphere(wants_sphere, pixel, sample, site, A.key0, A.key1);
@@ -460,6 +505,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) k_render_spheres(c
 
 // ---------------------------------------------------------------- first-hit kernel
 // One lane per pixel centre; definition in raytracing_amd.h (rt_first_hit).
+template <bool TIMED>
 __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A) {
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
     __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
@@ -485,24 +531,28 @@ __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A)
     const d3 d = llc + s * hor + t * ver - origin - offset;
     uint32_t ovf = 0;
     ProbeClock clk;
-    const Hit h = closest_hit(A.scene, o, d, on, A.exact_only != 0, list, rows, lane, ovf, clk);
-    if (on) A.ids[pixel] = h.id;
+    const Hit h = closest_hit<TIMED>(A.scene, o, d, C.time0, on, A.exact_only != 0, list, rows, lane, ovf, clk);
+    if (on) A.ids[pixel] = (TIMED && h.id >= 0) ? A.scene.top_of[h.id] : h.id;
 }
 
-hipError_t launch_render_spheres(const RenderArgs& args, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_render_spheres, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+hipError_t launch_render_spheres(const RenderArgs& args, bool timed, int blocks, hipStream_t stream) {
+    if (timed) hipLaunchKernelGGL(k_render_spheres<true>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(k_render_spheres<false>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
-hipError_t launch_first_hit_spheres(const FirstHitArgs& args, hipStream_t stream) {
+hipError_t launch_first_hit_spheres(const FirstHitArgs& args, bool timed, hipStream_t stream) {
     const uint32_t npix = (uint32_t)args.width * (uint32_t)args.height;
-    hipLaunchKernelGGL(k_first_hit_spheres, dim3((npix + 255u) / 256u), dim3(256), 0, stream, args);
+    if (timed) hipLaunchKernelGGL(k_first_hit_spheres<true>, dim3((npix + 255u) / 256u), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(k_first_hit_spheres<false>, dim3((npix + 255u) / 256u), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 
-int render_spheres_blocks_per_cu() {
+int render_spheres_blocks_per_cu(bool timed) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres, 256, 0) != hipSuccess || n < 1) n = 2;
+    const hipError_t e = timed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<true>, 256, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<false>, 256, 0);
+    if (e != hipSuccess || n < 1) n = 2;
     return n;
 }
 

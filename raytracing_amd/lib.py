@@ -53,6 +53,8 @@ def load():
     L.rt_context_set_exact_only.argtypes = [ctx_p, C.c_int]
     L.rt_context_set_force_graph.restype = C.c_int
     L.rt_context_set_force_graph.argtypes = [ctx_p, C.c_int]
+    L.rt_context_kernels_for.restype = C.c_int
+    L.rt_context_kernels_for.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc)]
     L.rt_context_take_stats.restype = C.c_int
     L.rt_context_take_stats.argtypes = [ctx_p, C.POINTER(abi.rt_stats)]
     L.rt_first_hit.restype = C.c_int
@@ -75,7 +77,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "rt_get_device_count", "rt_context_create", "rt_context_destroy", "rt_scene_upload", "rt_render",
     "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_set_force_graph",
-    "rt_context_take_stats",
+    "rt_context_take_stats", "rt_context_kernels_for",
     "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
 ]
 
@@ -153,6 +155,10 @@ class Context:
     def set_force_graph(self, on: bool):
         """Takes effect at the next upload()."""
         self._check(self._L.rt_context_set_force_graph(self._h, int(bool(on))), "rt_context_set_force_graph")
+
+    def kernels_for(self, cam) -> int:
+        """abi.RT_KERNELS_* : the kernel family that renders the uploaded world for this camera."""
+        return int(self._L.rt_context_kernels_for(self._h, C.byref(cam)))
 
     def render(self, cam, params):
         """-> (double colour sums [H,W,3], stats dict)"""

@@ -65,17 +65,23 @@ def test_scene_first_hit_ids(ctx, kat_b2, name):
 
 @pytest.mark.parametrize("name", ["bouncing", "cornell_box", "cornell_smoke", "two_perlin", "final"])
 def test_specialised_and_general_kernel_variants_agree(ctx, kat_b2, name, monkeypatch):
-    """A world runs the kernel variant compiled for the features it uses; the general variant gives the same bits."""
+    """A world runs the kernel variant compiled for the features it uses; the general variant gives the same bits.
+    (Graph walk forced: the bouncing spheres would otherwise run on the sphere-list kernels.)"""
     k = kat_b2[name]
     scene = load_b2(name)
     cam = camera_b2(k, lib.camera)
     p = abi.render_params(64, 48, 4, 50, seed=12)
-    ctx.upload(scene)
-    a, sa = ctx.render(cam, p)
-    monkeypatch.setenv("RT_SCENE_VARIANT", "all")
-    ctx.upload(scene)
-    b, sb = ctx.render(cam, p)
-    monkeypatch.delenv("RT_SCENE_VARIANT")
+    ctx.set_force_graph(True)
+    try:
+        ctx.upload(scene)
+        assert ctx.kernels_for(cam) == abi.RT_KERNELS_SCENE_GRAPH
+        a, sa = ctx.render(cam, p)
+        monkeypatch.setenv("RT_SCENE_VARIANT", "all")
+        ctx.upload(scene)
+        b, sb = ctx.render(cam, p)
+        monkeypatch.delenv("RT_SCENE_VARIANT")
+    finally:
+        ctx.set_force_graph(False)
     ctx.upload(scene)
     assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
 
