@@ -47,6 +47,9 @@ struct rt_context {
     bool spheres_timed = false;
     double sweep_lo = 0.0, sweep_hi = 0.0;
     int sphere_set_max = 2048;  // above this many spheres the BVH walk of the graph kernels wins (RT_SPHERE_SET_MAX)
+    // inside a graph, a BVH subtree of at least / at most this many static spheres is evaluated as a sphere set
+    // (RT_SUBTREE_SET_MIN, RT_SUBTREE_SET_MAX; a minimum above the maximum turns sets off)
+    int subtree_set_min = 64, subtree_set_max = 4096;
     SphereListDev spheres{};
     SceneDev graph{};
     std::vector<void*> scene_allocs;  // device memory owned by the current scene
@@ -265,6 +268,8 @@ struct SphereSetWalk {
     int max_spheres;
     std::vector<int>& prims;
     std::vector<int>& tops;
+    bool static_only;   // moving spheres disqualify the subtree
+    bool any_material;  // the caller shades by node id: every material and texture is fine
     struct Box {
         double lo[3], hi[3];
     };
@@ -293,12 +298,14 @@ struct SphereSetWalk {
         const rt_node& n = sc->nodes[idx];
         if (n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_MOVING_SPHERE) {
             const rt_material& m = sc->materials[n.material];
-            if (m.kind == RT_MAT_LAMBERTIAN) {
+            if (any_material) {
+            } else if (m.kind == RT_MAT_LAMBERTIAN) {
                 if (!texture_fits(m.texture, 0)) return false;
             } else if (m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
                 return false;
             }
             if ((int)prims.size() >= max_spheres) return false;
+            if (static_only && n.kind != RT_NODE_SPHERE) return false;
             if (n.kind == RT_NODE_SPHERE) {
                 box = around(n.p, n.p[3]);
             } else {  // p = centre0, centre1, time0, time1, radius
@@ -342,7 +349,7 @@ struct SphereSetWalk {
     }
 };
 static bool collect_sphere_set(const rt_scene_desc* sc, int max_spheres, std::vector<int>& prims, std::vector<int>& tops) {
-    SphereSetWalk w{sc, max_spheres, prims, tops};
+    SphereSetWalk w{sc, max_spheres, prims, tops, false, false};
     SphereSetWalk::Box box;
     return w.walk(sc->root, -1, box);
 }
@@ -368,26 +375,25 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
     return mats;
 }
 
-// Lays out the spheres `prims` (node ids, in list order) for the sphere kernels.  tops == nullptr: a book-1 list.
-// Otherwise the book-2 layout: motion records, textures, and a screening image in which a moving sphere is
-// replaced by a sphere bounding its sweep over its own [time0, time1].
-static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims,
-                              const std::vector<int>* tops) {
+// Device image of the spheres `prims` (node ids, in list order) for the screening + exact passes.  With `timed`
+// every sphere also gets a motion record, and the screening image holds, for a moving sphere, a sphere that bounds
+// its sweep over its own [time0, time1]; sweep_lo / sweep_hi return the interval common to all moving spheres.
+static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, bool timed,
+                            SphereSetDev& S, double& sweep_lo, double& sweep_hi) {
     const int n = (int)prims.size();
-    const bool timed = tops != nullptr;
     const int n_pairs = (n + 1) / 2;
     const int n_chunks = std::max(1, (n_pairs + 255) / 256);
     std::vector<SpherePair> screen((size_t)n_chunks * 256);  // whole chunks: the sparse walk reads 4 pairs per lane
     std::vector<SphereExact> exact((size_t)std::max(1, n));
     std::vector<SphereMotion> motion(timed ? (size_t)std::max(1, n) : 0);
-    std::vector<int32_t> material_of((size_t)std::max(1, n));
     for (auto& s : screen) {  // padding never yields a candidate: q = -huge
         for (int h = 0; h < 2; ++h) {
             s.cx[h] = s.cy[h] = s.cz[h] = 0.0f;
             s.k[h] = 3.0e38f;
         }
     }
-    double sweep_lo = -INFINITY, sweep_hi = INFINITY;
+    sweep_lo = -INFINITY;
+    sweep_hi = INFINITY;
     for (int i = 0; i < n; ++i) {
         const rt_node& nd = sc->nodes[prims[(size_t)i]];
         double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
@@ -406,7 +412,6 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
             cz += 0.5 * dz;
             r = (std::fabs(nd.p[8]) + 0.5 * std::sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-6) + 1e-300;
         }
-        material_of[i] = nd.material;
         const double cc = cx * cx + cy * cy + cz * cz, rr = r * r;
         const double k = cc - rr - 0x1p-18 * (cc + rr);
         // round k toward -inf so the float image never shrinks the margin
@@ -418,6 +423,26 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
         sp.cz[i & 1] = (float)cz;
         sp.k[i & 1] = kf;
     }
+    S = SphereSetDev{};
+    int rc;
+    if ((rc = to_device(ctx, screen, &S.screen)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, exact, &S.exact)) != RT_OK) return rc;
+    if (timed && (rc = to_device(ctx, motion, &S.motion)) != RT_OK) return rc;
+    S.n = n;
+    S.n_full_groups = n / SCREEN_GROUP;
+    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
+    S.n_chunks = n_chunks;
+    return RT_OK;
+}
+
+// Lays out a world of spheres for the sphere kernels.  tops == nullptr: a book-1 list; otherwise the book-2 layout
+// (motion records, textures, top-level object of every sphere).
+static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims,
+                              const std::vector<int>* tops) {
+    const int n = (int)prims.size();
+    const bool timed = tops != nullptr;
+    std::vector<int32_t> material_of((size_t)std::max(1, n));
+    for (int i = 0; i < n; ++i) material_of[i] = sc->nodes[prims[(size_t)i]].material;
     std::vector<MaterialDev> mats = device_materials(sc);
     // the sphere kernels read a solid albedo from the material itself; tex stays only where a checker must be evaluated
     for (int i = 0; i < sc->n_materials; ++i) {
@@ -430,25 +455,17 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
     SphereListDev& S = ctx->spheres;
     S = SphereListDev{};
     int rc;
-    if ((rc = to_device(ctx, screen, &S.screen)) != RT_OK) return rc;
-    if ((rc = to_device(ctx, exact, &S.exact)) != RT_OK) return rc;
+    if ((rc = build_sphere_set(ctx, sc, prims, timed, S.set, ctx->sweep_lo, ctx->sweep_hi)) != RT_OK) return rc;
     if ((rc = to_device(ctx, material_of, &S.material_of)) != RT_OK) return rc;
     if ((rc = to_device(ctx, mats, &S.materials)) != RT_OK) return rc;
     if (timed) {
         std::vector<int32_t> top_of(tops->begin(), tops->end());
-        if ((rc = to_device(ctx, motion, &S.motion)) != RT_OK) return rc;
         if ((rc = to_device(ctx, top_of, &S.top_of)) != RT_OK) return rc;
         S.textures = ctx->graph.textures;  // uploaded with the graph of the same world
     }
-    S.n = n;
-    S.n_full_groups = n / SCREEN_GROUP;
-    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
-    S.n_chunks = n_chunks;
     S.sky_mode = sc->sky_mode;
     for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
     ctx->spheres_timed = timed;
-    ctx->sweep_lo = sweep_lo;
-    ctx->sweep_hi = sweep_hi;
     ctx->path = PATH_SPHERE_LIST;
     return RT_OK;
 }
@@ -534,6 +551,30 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
         }
         nodes[i] = d;
     }
+    // BVH subtrees of static spheres directly under a top-level object's instance chain become sphere sets
+    std::vector<SphereSetDev> sets;
+    std::vector<int32_t> set_nodes;
+    {
+        const rt_node& root = sc->nodes[sc->root];
+        for (int i = 0; i < root.child1 && ctx->subtree_set_min <= ctx->subtree_set_max; ++i) {
+            int idx = sc->children[root.child0 + i];
+            while (sc->nodes[idx].kind == RT_NODE_TRANSLATE || sc->nodes[idx].kind == RT_NODE_ROTATE_Y) idx = sc->nodes[idx].child0;
+            if (sc->nodes[idx].kind != RT_NODE_BVH) continue;
+            std::vector<int> prims, tops;
+            SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true, true};
+            SphereSetWalk::Box box;
+            if (!w.walk(idx, i, box) || (int)prims.size() < ctx->subtree_set_min) continue;
+            SphereSetDev sd;
+            double lo, hi;
+            const int rc = build_sphere_set(ctx, sc, prims, false, sd, lo, hi);
+            if (rc != RT_OK) return rc;
+            nodes[(size_t)idx].kind = DEV_NODE_SPHERE_SET;  // p keeps the subtree's box
+            nodes[(size_t)idx].a = (int32_t)sets.size();
+            nodes[(size_t)idx].b = (int32_t)set_nodes.size();
+            sets.push_back(sd);
+            set_nodes.insert(set_nodes.end(), prims.begin(), prims.end());
+        }
+    }
     std::vector<int32_t> children(sc->children, sc->children + sc->n_children);
     const std::vector<MaterialDev> mats = device_materials(sc);
     std::vector<TextureDev> texs((size_t)sc->n_textures);
@@ -572,6 +613,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     if ((rc = to_device(ctx, texs, &G.textures)) != RT_OK) return rc;
     if ((rc = to_device(ctx, perlins, &G.perlins)) != RT_OK) return rc;
     if ((rc = to_device(ctx, images, &G.images)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, sets, &G.sets)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, set_nodes, &G.set_nodes)) != RT_OK) return rc;
     std::vector<int32_t> lights;
     bool isotropic = false;
     for (int i = 0; i < sc->n_materials; ++i) isotropic = isotropic || sc->materials[i].kind == RT_MAT_ISOTROPIC;
@@ -589,6 +632,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     // which kernel variant the world needs (a superset is always valid; RT_SCENE_VARIANT=all forces the general one)
     int features = 0;
     for (int i = 0; i < sc->n_nodes; ++i) features |= scene_feature_bit_for_node(sc->nodes[i].kind);
+    if (!sets.empty()) features |= scene_feature_bit_for_node(DEV_NODE_SPHERE_SET);
     for (int i = 0; i < sc->n_textures; ++i) features |= scene_feature_bit_for_texture(sc->textures[i].kind);
     for (int i = 0; i < sc->n_materials; ++i) features |= scene_feature_bit_for_material(sc->materials[i].kind);
     if (const char* v = std::getenv("RT_SCENE_VARIANT")) {
@@ -663,6 +707,8 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu(false);
     ctx->blocks_per_cu_spheres_timed = render_spheres_blocks_per_cu(true);
     if (const char* s = std::getenv("RT_SPHERE_SET_MAX")) ctx->sphere_set_max = std::min(65535, std::max(0, std::atoi(s)));
+    if (const char* s = std::getenv("RT_SUBTREE_SET_MIN")) ctx->subtree_set_min = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("RT_SUBTREE_SET_MAX")) ctx->subtree_set_max = std::min(65535, std::max(0, std::atoi(s)));
     if (const char* s = std::getenv("RT_PIXEL_PASS")) ctx->pixel_pass_min_samples = std::atoi(s) != 0 ? 0 : 0x7FFFFFFF;
     if (const char* s = std::getenv("RT_BLOCKS_PER_CU")) {
         int v = std::atoi(s);

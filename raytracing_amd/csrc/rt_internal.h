@@ -42,19 +42,22 @@ struct MaterialDev {
 constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
 
-struct SphereListDev {
+struct SphereSetDev {
     int32_t n;         // spheres in list order (= object ids)
     int32_t n_full_groups;  // n / SCREEN_GROUP: groups screened by the unrolled loop
     int32_t n_tail_pairs;   // pairs of the last, partial group (0..15); an odd sphere is padded
     int32_t n_chunks;       // 256-pair chunks of the screen image (padded with never-hit pairs to a whole chunk)
     const SpherePair* screen;
     const SphereExact* exact;
+    const SphereMotion* motion;  // book-2 sphere worlds only, else null
+};
+struct SphereListDev {
+    SphereSetDev set;
     const int32_t* material_of;
     const MaterialDev* materials;
     int32_t sky_mode;
     double background[3];
-    // book-2 sphere worlds only (null / 0 for a book-1 list)
-    const SphereMotion* motion;
+    // book-2 sphere worlds only (null for a book-1 list)
     const TextureDev* textures;        // solid and checker textures of the lambertian materials
     const int32_t* top_of;              // per sphere: index within the root list of the top-level object holding it
 };
@@ -99,11 +102,16 @@ struct FirstHitArgs {
 // Device-only node kind: a box whose six sides are those the reference's constructor derives from its corners and are
 // numbered consecutively; the traversal tests the sides from the corners in one step.
 constexpr int DEV_NODE_BOX6 = 64;
+// Device-only node kind: a BVH subtree whose leaves are all static spheres and whose boxes enclose them, directly
+// under a top-level object's translate / rotate_y chain.  The traversal tests the subtree's own box, then finds the
+// closest of its spheres with the screening + exact passes of the sphere-list kernels instead of walking the tree.
+constexpr int DEV_NODE_SPHERE_SET = 65;
 struct SceneNode {
     int32_t kind;  // RT_NODE_* or DEV_NODE_BOX6
     int32_t a;     // sphere/rect/medium: material; LIST/BOX: first child slot; BVH: left; instance/medium: child
     int32_t b;     // LIST/BOX: child count; BVH: right; medium: boundary node
     int32_t c;     // moving sphere: index of {time0, time1, radius} in extra[]; DEV_NODE_BOX6: node id of the first side
+                   // DEV_NODE_SPHERE_SET: a = index in sets[], b = first slot in set_nodes[], p = the subtree's box
     double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | box: corners | translate: offset
                    // | rotate_y: sin, cos | medium: neg_inv_density
 };
@@ -128,6 +136,8 @@ struct SceneDev {
     const TextureDev* textures;
     const rt_perlin* perlins;
     const ImageDev* images;
+    const SphereSetDev* sets;  // one per DEV_NODE_SPHERE_SET node
+    const int32_t* set_nodes;  // node ids of the spheres of all sets, in each set's list order
     int32_t sky_mode;
     int32_t n_lights;                  // light shapes sampled under RT_RENDER_IMPORTANCE
     int32_t lights[MAX_LIGHT_SHAPES];  // their node ids (xz_rect or sphere, world space)
@@ -135,6 +145,9 @@ struct SceneDev {
     double background[3];
 };
 constexpr int STACK_CAP = 40;   // traversal stack slots per lane (uint32 each, in LDS)
+// While a sphere set is evaluated, the slots above this one hold its candidate lists: a top-level object that contains
+// a set may not need more stack than this (instances chains are at most XF_DEPTH_CAP deep, so it never does).
+constexpr int SET_STACK_SLOTS = 7;
 constexpr int XF_DEPTH_CAP = 4;  // nested translate / rotate_y levels
 
 struct SceneRenderArgs {

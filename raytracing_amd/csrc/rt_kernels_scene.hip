@@ -20,6 +20,7 @@
 #include "rt_device_common.h"
 #include "rt_internal.h"
 #include "rt_render_common.h"
+#include "rt_sphere_screen.h"
 
 namespace rtd {
 
@@ -44,8 +45,10 @@ enum : int {
     F_ALL = 127,
     F_IS = 128,      // ray_color of book 3: light sampled by importance (RT_RENDER_IMPORTANCE); not part of F_ALL
     F_FLIP = 256,    // flip_face wrappers (book 3); not part of F_ALL, implies the instance machinery (F_XF)
-    F_EVERY = F_ALL | F_FLIP,
+    F_SET = 512,     // BVH subtrees of spheres evaluated as sphere sets (DEV_NODE_SPHERE_SET); not part of F_ALL
+    F_EVERY = F_ALL | F_FLIP | F_SET,
 };
+static_assert(SET_STACK_SLOTS * 64 + CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "candidate lists of a sphere set overlay the upper stack slots");
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
 
 struct Ray {
@@ -331,10 +334,12 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             atomicAdd(&g_probe_total[13], (unsigned long long)__popcll(ballot(sp > 0)));
         }
 #endif
+        int pending_set = -1;  // sphere-set node this lane has reached (its box is hit); evaluated by the whole wave below
         if (sp > 0) {
             const uint32_t entry = stack[(--sp) * 64 + lane];
             const int e = (int)(entry & 0xFFFFu);
             const uint32_t tag = entry >> 16;
+            bool leaving = false;
             if constexpr ((F & F_XF) != 0) {
                 if (tag >= END_XF_TRANSLATE) {  // leave instance node e: back to the ray of the level above
                     cur_xf = S.parent_xf[e];
@@ -343,9 +348,11 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
                         a = len2(cur.d);
                     }
-                    continue;
+                    if constexpr ((F & F_SET) == 0) continue;
+                    leaving = true;  // with sets, every lane must reach the wave-level part of the trip
                 }
             }
+            if (!leaving) {
             const SceneNode n = S.nodes[e];
             const int kind = n.kind;
 #ifdef RT_SCENE_PROBE
@@ -379,6 +386,8 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = n.c + side;
                     h.xf = cur_xf;
                 }
+            } else if ((F & F_SET) != 0 && kind == DEV_NODE_SPHERE_SET) {
+                if (hit_aabb(n.p, cur, inv, T_MIN, h.t)) pending_set = e;  // bvh_node::hit's own test, B2/bvh.h:98-99
             } else if ((F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM) {
                 medium_hit<F>(S, n, e, cur, cur_xf, tm, g, h);
             } else {
@@ -388,6 +397,31 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = e;
                     h.xf = cur_xf;
                 }
+            }
+            }
+        }
+        if constexpr ((F & F_SET) != 0) {
+            // Sphere sets are evaluated by the wave as a whole, one set at a time (the lanes of a trip are inside one
+            // top-level object, so normally they all wait at the same set).  The subtree keeps the smallest root in
+            // [t_min, closest so far] whatever order its leaves are tested in (B2/bvh.h:97-106): so does the list.
+            for (uint64_t pend = ballot(pending_set >= 0); pend != 0ull;) {
+                const int node = __builtin_amdgcn_readlane(pending_set, __builtin_ctzll(pend));
+                const bool mine = pending_set == node;
+                const int set_index = __builtin_amdgcn_readfirstlane(S.nodes[node].a);
+                const int first_slot = __builtin_amdgcn_readfirstlane(S.nodes[node].b);
+                const SphereSetDev set = S.sets[set_index];
+                uint16_t* list = (uint16_t*)(stack + SET_STACK_SLOTS * 64);
+                uint32_t* rows = stack + SET_STACK_SLOTS * 64 + CAND_CAP * 32;
+                uint32_t overflowed = 0;
+                ProbeClock clk;
+                const SetHit sh = closest_hit<false>(set, cur.o, cur.d, 0.0, h.t, mine, false, list, rows, lane, overflowed, clk);
+                if (mine && sh.id >= 0) {
+                    h.t = sh.t;
+                    h.node = S.set_nodes[first_slot + sh.id];
+                    h.xf = cur_xf;
+                }
+                if (mine) pending_set = -1;
+                pend &= ~ballot(mine);
             }
         }
     }
@@ -827,6 +861,9 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
 #ifndef RT_SCENE_WAVES_B
 #define RT_SCENE_WAVES_B 3
 #endif
+#ifndef RT_SCENE_WAVES_SET
+#define RT_SCENE_WAVES_SET 3
+#endif
 constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
 constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
 constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE;  // textured spheres and lights
@@ -841,6 +878,7 @@ static const SceneVariant g_variants[] = {
     {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
     {V_C, k_render_scene<V_C, 2>},
     {F_ALL, k_render_scene<F_ALL, RT_SCENE_MIN_WAVES>},
+    {F_ALL | F_SET, k_render_scene<F_ALL | F_SET, RT_SCENE_WAVES_SET>},
     {F_EVERY, k_render_scene<F_EVERY, RT_SCENE_MIN_WAVES>},
     {V_IS, k_render_scene<V_IS, 2>},
     {F_EVERY | F_IS, k_render_scene<F_EVERY | F_IS, 2>},
@@ -892,6 +930,7 @@ int scene_feature_bit_for_node(int kind) {
     case RT_NODE_ROTATE_Y: return F_XF;
     case RT_NODE_FLIP_FACE: return F_XF | F_FLIP;
     case RT_NODE_MEDIUM: return F_MEDIUM;
+    case DEV_NODE_SPHERE_SET: return F_SET;
     default: return 0;
     }
 }

@@ -213,3 +213,119 @@ def test_bouncing_spheres_full_size_properties(ctx, kat_b2):
     p2, _ = ctx.render(cam, abi.render_params(240, 135, 4, 50, seed=9, sample_begin=100))
     assert np.array_equal(np.rint(p1 * FRAC).astype(np.int64) + np.rint(p2 * FRAC).astype(np.int64),
                           np.rint(whole * FRAC).astype(np.int64))
+
+
+# ---------------------------------------------------------------- sphere subtrees inside a general graph
+def instanced_cluster_world():
+    """root list [ground, light rect, translate(rotate_y(bvh of 5 static spheres)), bvh of 2 spheres, glass sphere]:
+    not a sphere world (the rectangle), but both BVH subtrees hold only static spheres."""
+    import math
+    tex = np.zeros(3, abi.TEXTURE_DTYPE)
+    tex["kind"] = abi.RT_TEX_SOLID
+    tex["p"][0][:3] = (0.5, 0.6, 0.4)
+    tex["p"][1][:3] = (7.0, 7.0, 7.0)
+    tex["p"][2][:3] = (0.73, 0.73, 0.73)
+    mat = np.zeros(5, abi.MATERIAL_DTYPE)
+    mat["kind"] = [abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_DIFFUSE_LIGHT, abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL, abi.RT_MAT_DIELECTRIC]
+    mat["texture"] = [0, 1, 2, -1, -1]
+    mat["albedo"][3] = (0.8, 0.8, 0.9)
+    mat["param"] = [0, 0, 0, 0.1, 1.5]
+    nodes = np.zeros(20, abi.NODE_DTYPE)
+    nodes["material"] = -1
+
+    def sphere(i, c, r, m):
+        nodes[i]["kind"], nodes[i]["material"] = abi.RT_NODE_SPHERE, m
+        nodes[i]["p"][:4] = (*c, r)
+
+    def box(i):
+        n = nodes[i]
+        if n["kind"] == abi.RT_NODE_SPHERE:
+            c, r = n["p"][:3], n["p"][3]
+            return c - r, c + r
+        lo_l, hi_l = box(n["child0"])
+        lo_r, hi_r = box(n["child1"])
+        return np.minimum(lo_l, lo_r), np.maximum(hi_l, hi_r)
+
+    def bvh(i, left, right):
+        nodes[i]["kind"] = abi.RT_NODE_BVH
+        nodes[i]["child0"], nodes[i]["child1"] = left, right
+        lo, hi = box(i)
+        nodes[i]["p"][:6] = (*lo, *hi)
+
+    children = np.array([1, 2, 3, 14, 17], dtype=np.int32)
+    nodes[0]["kind"], nodes[0]["child0"], nodes[0]["child1"] = abi.RT_NODE_LIST, 0, 5
+    sphere(1, (0, -1000, 0), 1000, 0)
+    nodes[2]["kind"], nodes[2]["material"] = abi.RT_NODE_XZ_RECT, 1
+    nodes[2]["p"][:5] = (-2, 2, -2, 2, 6)
+    # the cluster, in its own frame around the origin
+    sphere(6, (-0.8, 0.5, 0.0), 0.5, 2)
+    sphere(7, (0.4, 0.4, 0.6), 0.4, 3)
+    sphere(8, (0.3, 0.45, -0.7), 0.45, 2)
+    sphere(9, (0.0, 1.3, 0.0), 0.4, 4)
+    sphere(10, (1.3, 0.3, 0.1), 0.3, 2)
+    bvh(11, 6, 7)
+    bvh(12, 8, 9)
+    bvh(13, 12, 10)
+    bvh(5, 11, 13)
+    theta = math.radians(25.0)
+    nodes[4]["kind"], nodes[4]["child0"] = abi.RT_NODE_ROTATE_Y, 5
+    nodes[4]["p"][:2] = (math.sin(theta), math.cos(theta))
+    nodes[3]["kind"], nodes[3]["child0"] = abi.RT_NODE_TRANSLATE, 4
+    nodes[3]["p"][:3] = (-1.5, 0.0, 1.0)
+    sphere(15, (2.2, 0.5, -1.0), 0.5, 3)
+    sphere(16, (2.6, 0.4, 0.4), 0.4, 2)
+    bvh(14, 15, 16)
+    sphere(17, (0.8, 0.6, 2.6), 0.6, 4)
+    return abi.Scene(0, nodes[:18].copy(), children, mat, tex, np.zeros(0, abi.PERLIN_DTYPE),
+                     sky_mode=abi.RT_SKY_BACKGROUND, background=(0.05, 0.05, 0.08))
+
+
+def render_with_subtree_sets(monkeypatch, scene, cam, p, set_min, fh=(80, 60)):
+    monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))  # read when a context is created
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        assert c.kernels_for(cam) == abi.RT_KERNELS_SCENE_GRAPH
+        img, st = c.render(cam, p)
+        ids = c.first_hit(cam, *fh)
+    finally:
+        c.close()
+    return img, st, ids
+
+
+def test_sphere_subtrees_inside_a_graph_match_oracle(monkeypatch):
+    scene = instanced_cluster_world()
+    cam, ocam = cam_for(0.0, 1.0), cam_for(0.0, 1.0, ob.camera)
+    p = abi.render_params(64, 48, 6, 50, seed=31)
+    want, ost = oracle_sums(scene, ocam, p)
+    want_ids = ob.first_hit(scene, ocam, 80, 60)
+    assert {2, 3, 4} <= set(np.unique(want_ids))  # both clusters are in view
+    for set_min in (2, 5, 1000):  # both subtrees as sets; the five-sphere one only; none
+        got, st, ids = render_with_subtree_sets(monkeypatch, scene, cam, p, set_min)
+        assert st["rays"] == ost["rays"], set_min
+        assert np.array_equal(got, want), (set_min, np.abs(got - want).max())
+        assert np.array_equal(ids, want_ids), set_min
+
+
+def test_subtree_with_a_short_box_keeps_its_tree(monkeypatch):
+    scene = instanced_cluster_world()
+    scene.nodes[13]["p"][4] -= 0.5  # cuts the top sphere: the reference culls there, a list of the leaves would not
+    cam, ocam = cam_for(0.0, 1.0), cam_for(0.0, 1.0, ob.camera)
+    p = abi.render_params(64, 48, 6, 50, seed=31)
+    want, ost = oracle_sums(scene, ocam, p)
+    got, st, ids = render_with_subtree_sets(monkeypatch, scene, cam, p, 2)
+    assert st["rays"] == ost["rays"] and np.array_equal(got, want)
+    assert np.array_equal(ids, ob.first_hit(scene, ocam, 80, 60))
+
+
+def test_final_scene_sphere_cube_as_a_set(monkeypatch, kat_b2):
+    """Config 4: the cube of 1000 spheres under translate(rotate_y(bvh)) is one sphere set; same bits without."""
+    k = kat_b2["final"]
+    scene = load_b2("final")
+    cam = camera_b2(k, lib.camera)
+    p = abi.render_params(200, 200, 8, 50, seed=4)
+    a, sa, ids_a = render_with_subtree_sets(monkeypatch, scene, cam, p, 64, fh=(200, 200))
+    b, sb, ids_b = render_with_subtree_sets(monkeypatch, scene, cam, p, 100000, fh=(200, 200))
+    assert sa["rays"] == sb["rays"] and np.array_equal(a, b) and np.array_equal(ids_a, ids_b)
+    rows = ob.render_rows(scene, camera_b2(k), p, 60, 62, has_time=True) / FRAC
+    assert np.array_equal(a[60:62], rows)
