@@ -47,7 +47,7 @@ struct rt_context {
     bool spheres_timed = false;
     double sweep_lo = 0.0, sweep_hi = 0.0;
     int sphere_set_max = 2048;  // above this many spheres the BVH walk of the graph kernels wins (RT_SPHERE_SET_MAX)
-    // inside a graph, a BVH subtree of at least / at most this many static spheres is evaluated as a sphere set
+    // inside a graph, a BVH subtree of at least / at most this many static spheres and boxes is evaluated as a leaf set
     // (RT_SUBTREE_SET_MIN, RT_SUBTREE_SET_MAX; a minimum above the maximum turns sets off)
     int subtree_set_min = 64, subtree_set_max = 4096;
     SphereListDev spheres{};
@@ -256,6 +256,8 @@ static bool is_book1_sphere_list(const rt_scene_desc* sc) {
     return true;
 }
 
+static bool is_reference_box(const rt_scene_desc* sc, const rt_node& n);
+
 // Leaves of a world whose only primitives are spheres and moving spheres, nested in lists and BVH nodes in any way,
 // with materials the sphere kernels shade (lambertian over solid / checker textures, metal, dielectric).  A closest
 // hit does not depend on the order of the tests, so such a world can be rendered as the list of its leaves --
@@ -268,8 +270,8 @@ struct SphereSetWalk {
     int max_spheres;
     std::vector<int>& prims;
     std::vector<int>& tops;
-    bool static_only;   // moving spheres disqualify the subtree
-    bool any_material;  // the caller shades by node id: every material and texture is fine
+    bool graph_leaves;  // leaves of a leaf set inside a graph: static spheres of any material (shading goes by node id)
+                        // and boxes whose sides are those box::box derives; moving spheres disqualify the subtree
     struct Box {
         double lo[3], hi[3];
     };
@@ -298,14 +300,14 @@ struct SphereSetWalk {
         const rt_node& n = sc->nodes[idx];
         if (n.kind == RT_NODE_SPHERE || n.kind == RT_NODE_MOVING_SPHERE) {
             const rt_material& m = sc->materials[n.material];
-            if (any_material) {
+            if (graph_leaves) {
             } else if (m.kind == RT_MAT_LAMBERTIAN) {
                 if (!texture_fits(m.texture, 0)) return false;
             } else if (m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
                 return false;
             }
             if ((int)prims.size() >= max_spheres) return false;
-            if (static_only && n.kind != RT_NODE_SPHERE) return false;
+            if (graph_leaves && n.kind != RT_NODE_SPHERE) return false;
             if (n.kind == RT_NODE_SPHERE) {
                 box = around(n.p, n.p[3]);
             } else {  // p = centre0, centre1, time0, time1, radius
@@ -317,6 +319,16 @@ struct SphereSetWalk {
                     at1[k] = n.p[k] + ((time1 - time0) / (time1 - time0)) * (n.p[3 + k] - n.p[k]);
                 }
                 box = join(around(at0, n.p[8]), around(at1, n.p[8]));
+            }
+            prims.push_back(idx);
+            tops.push_back(top);
+            return true;
+        }
+        if (graph_leaves && n.kind == RT_NODE_BOX) {  // box::bounding_box, B2/box.h:20-23
+            if (!is_reference_box(sc, n) || (int)prims.size() >= max_spheres) return false;
+            for (int k = 0; k < 3; ++k) {
+                box.lo[k] = n.p[k];
+                box.hi[k] = n.p[3 + k];
             }
             prims.push_back(idx);
             tops.push_back(top);
@@ -349,7 +361,7 @@ struct SphereSetWalk {
     }
 };
 static bool collect_sphere_set(const rt_scene_desc* sc, int max_spheres, std::vector<int>& prims, std::vector<int>& tops) {
-    SphereSetWalk w{sc, max_spheres, prims, tops, false, false};
+    SphereSetWalk w{sc, max_spheres, prims, tops, false};
     SphereSetWalk::Box box;
     return w.walk(sc->root, -1, box);
 }
@@ -432,6 +444,36 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
     S.n_full_groups = n / SCREEN_GROUP;
     S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
     S.n_chunks = n_chunks;
+    return RT_OK;
+}
+
+// Float image of the boxes `prims` (RT_NODE_BOX node ids) for the slab screen: lower corners rounded down, upper
+// corners rounded up, padded to whole screening groups.
+static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, BoxSetDev& B) {
+    const int n = (int)prims.size();
+    const int n_groups = std::max(1, (n + SCREEN_GROUP - 1) / SCREEN_GROUP);
+    std::vector<BoxPair> screen((size_t)n_groups * (SCREEN_GROUP / 2));
+    std::memset(screen.data(), 0, screen.size() * sizeof(BoxPair));
+    double coord_max = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const rt_node& nd = sc->nodes[prims[(size_t)i]];
+        BoxPair& bp = screen[(size_t)i / 2];
+        for (int k = 0; k < 3; ++k) {
+            // the corners as given are box_min / box_max (B2/box.h:28-30); order them in case they are not
+            const double lo = std::fmin(nd.p[k], nd.p[3 + k]), hi = std::fmax(nd.p[k], nd.p[3 + k]);
+            float lf = (float)lo, hf = (float)hi;
+            if ((double)lf > lo) lf = std::nextafterf(lf, -INFINITY);
+            if ((double)hf < hi) hf = std::nextafterf(hf, INFINITY);
+            bp.lo[k][i & 1] = lf;
+            bp.hi[k][i & 1] = hf;
+            coord_max = std::fmax(coord_max, std::fmax(std::fabs(lo), std::fabs(hi)));
+        }
+    }
+    B = BoxSetDev{};
+    int rc;
+    if ((rc = to_device(ctx, screen, &B.screen)) != RT_OK) return rc;
+    B.n = n;
+    B.coord_max = std::nextafterf((float)coord_max, INFINITY);
     return RT_OK;
 }
 
@@ -551,8 +593,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
         }
         nodes[i] = d;
     }
-    // BVH subtrees of static spheres directly under a top-level object's instance chain become sphere sets
-    std::vector<SphereSetDev> sets;
+    // BVH subtrees of static spheres and boxes directly under a top-level object's instance chain become leaf sets
+    std::vector<LeafSetDev> sets;
     std::vector<int32_t> set_nodes;
     {
         const rt_node& root = sc->nodes[sc->root];
@@ -561,18 +603,29 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             while (sc->nodes[idx].kind == RT_NODE_TRANSLATE || sc->nodes[idx].kind == RT_NODE_ROTATE_Y) idx = sc->nodes[idx].child0;
             if (sc->nodes[idx].kind != RT_NODE_BVH) continue;
             std::vector<int> prims, tops;
-            SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true, true};
+            SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true};
             SphereSetWalk::Box box;
             if (!w.walk(idx, i, box) || (int)prims.size() < ctx->subtree_set_min) continue;
-            SphereSetDev sd;
+            std::vector<int> spheres, boxes;
+            double coord_max = 0.0;
+            for (int id : prims) {
+                const rt_node& leaf = sc->nodes[id];
+                (leaf.kind == RT_NODE_BOX ? boxes : spheres).push_back(id);
+                if (leaf.kind == RT_NODE_BOX)
+                    for (int k = 0; k < 6; ++k) coord_max = std::fmax(coord_max, std::fabs(leaf.p[k]));
+            }
+            if (!(coord_max <= 1e6)) continue;  // the slab screen's bound assumes it (also rejects NaN)
+            LeafSetDev sd{};
             double lo, hi;
-            const int rc = build_sphere_set(ctx, sc, prims, false, sd, lo, hi);
+            int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, sd.spheres, lo, hi);
+            if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, sd.boxes);
             if (rc != RT_OK) return rc;
-            nodes[(size_t)idx].kind = DEV_NODE_SPHERE_SET;  // p keeps the subtree's box
+            nodes[(size_t)idx].kind = DEV_NODE_LEAF_SET;  // p keeps the subtree's box
             nodes[(size_t)idx].a = (int32_t)sets.size();
             nodes[(size_t)idx].b = (int32_t)set_nodes.size();
             sets.push_back(sd);
-            set_nodes.insert(set_nodes.end(), prims.begin(), prims.end());
+            set_nodes.insert(set_nodes.end(), spheres.begin(), spheres.end());
+            set_nodes.insert(set_nodes.end(), boxes.begin(), boxes.end());
         }
     }
     std::vector<int32_t> children(sc->children, sc->children + sc->n_children);
@@ -632,7 +685,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     // which kernel variant the world needs (a superset is always valid; RT_SCENE_VARIANT=all forces the general one)
     int features = 0;
     for (int i = 0; i < sc->n_nodes; ++i) features |= scene_feature_bit_for_node(sc->nodes[i].kind);
-    if (!sets.empty()) features |= scene_feature_bit_for_node(DEV_NODE_SPHERE_SET);
+    if (!sets.empty()) features |= scene_feature_bit_for_node(DEV_NODE_LEAF_SET);
     for (int i = 0; i < sc->n_textures; ++i) features |= scene_feature_bit_for_texture(sc->textures[i].kind);
     for (int i = 0; i < sc->n_materials; ++i) features |= scene_feature_bit_for_material(sc->materials[i].kind);
     if (const char* v = std::getenv("RT_SCENE_VARIANT")) {

@@ -51,6 +51,21 @@ struct SphereSetDev {
     const SphereExact* exact;
     const SphereMotion* motion;  // book-2 sphere worlds only, else null
 };
+// Screening image of axis-aligned boxes: two boxes interleaved component by component, like SpherePair.
+struct BoxPair {
+    float lo[3][2];  // rounded down
+    float hi[3][2];  // rounded up
+};
+struct BoxSetDev {
+    int32_t n;
+    float coord_max;  // largest |coordinate| of the boxes
+    const BoxPair* screen;  // padded to whole groups of SCREEN_GROUP boxes
+};
+// The leaves of a DEV_NODE_LEAF_SET node: spheres, then boxes.
+struct LeafSetDev {
+    SphereSetDev spheres;
+    BoxSetDev boxes;
+};
 struct SphereListDev {
     SphereSetDev set;
     const int32_t* material_of;
@@ -102,16 +117,18 @@ struct FirstHitArgs {
 // Device-only node kind: a box whose six sides are those the reference's constructor derives from its corners and are
 // numbered consecutively; the traversal tests the sides from the corners in one step.
 constexpr int DEV_NODE_BOX6 = 64;
-// Device-only node kind: a BVH subtree whose leaves are all static spheres and whose boxes enclose them, directly
-// under a top-level object's translate / rotate_y chain.  The traversal tests the subtree's own box, then finds the
-// closest of its spheres with the screening + exact passes of the sphere-list kernels instead of walking the tree.
-constexpr int DEV_NODE_SPHERE_SET = 65;
+// Device-only node kind: a BVH subtree whose leaves are all static spheres or boxes (of the DEV_NODE_BOX6 kind) and
+// whose node boxes enclose them, directly under a top-level object's translate / rotate_y chain.  The traversal
+// tests the subtree's own box, then finds the closest leaf with a wave-wide float screen (the sphere-list kernels'
+// for the spheres, a slab test for the boxes) and the reference's double-precision test of the few candidates,
+// instead of walking the tree.
+constexpr int DEV_NODE_LEAF_SET = 65;
 struct SceneNode {
     int32_t kind;  // RT_NODE_* or DEV_NODE_BOX6
     int32_t a;     // sphere/rect/medium: material; LIST/BOX: first child slot; BVH: left; instance/medium: child
     int32_t b;     // LIST/BOX: child count; BVH: right; medium: boundary node
     int32_t c;     // moving sphere: index of {time0, time1, radius} in extra[]; DEV_NODE_BOX6: node id of the first side
-                   // DEV_NODE_SPHERE_SET: a = index in sets[], b = first slot in set_nodes[], p = the subtree's box
+                   // DEV_NODE_LEAF_SET: a = index in sets[], b = first slot in set_nodes[], p = the subtree's box
     double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | box: corners | translate: offset
                    // | rotate_y: sin, cos | medium: neg_inv_density
 };
@@ -136,8 +153,8 @@ struct SceneDev {
     const TextureDev* textures;
     const rt_perlin* perlins;
     const ImageDev* images;
-    const SphereSetDev* sets;  // one per DEV_NODE_SPHERE_SET node
-    const int32_t* set_nodes;  // node ids of the spheres of all sets, in each set's list order
+    const LeafSetDev* sets;    // one per DEV_NODE_LEAF_SET node: the screening images of its leaves
+    const int32_t* set_nodes;  // node ids of the leaves of all sets: per set its spheres, then its boxes
     int32_t sky_mode;
     int32_t n_lights;                  // light shapes sampled under RT_RENDER_IMPORTANCE
     int32_t lights[MAX_LIGHT_SHAPES];  // their node ids (xz_rect or sphere, world space)

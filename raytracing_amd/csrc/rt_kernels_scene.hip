@@ -20,6 +20,7 @@
 #include "rt_device_common.h"
 #include "rt_internal.h"
 #include "rt_render_common.h"
+#include "rt_box_screen.h"
 #include "rt_sphere_screen.h"
 
 namespace rtd {
@@ -45,7 +46,7 @@ enum : int {
     F_ALL = 127,
     F_IS = 128,      // ray_color of book 3: light sampled by importance (RT_RENDER_IMPORTANCE); not part of F_ALL
     F_FLIP = 256,    // flip_face wrappers (book 3); not part of F_ALL, implies the instance machinery (F_XF)
-    F_SET = 512,     // BVH subtrees of spheres evaluated as sphere sets (DEV_NODE_SPHERE_SET); not part of F_ALL
+    F_SET = 512,     // BVH subtrees of spheres / boxes evaluated as leaf sets (DEV_NODE_LEAF_SET); not part of F_ALL
     F_EVERY = F_ALL | F_FLIP | F_SET,
 };
 static_assert(SET_STACK_SLOTS * 64 + CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "candidate lists of a sphere set overlay the upper stack slots");
@@ -334,7 +335,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             atomicAdd(&g_probe_total[13], (unsigned long long)__popcll(ballot(sp > 0)));
         }
 #endif
-        int pending_set = -1;  // sphere-set node this lane has reached (its box is hit); evaluated by the whole wave below
+        int pending_set = -1;  // leaf-set node this lane has reached (its box is hit); evaluated by the whole wave below
         if (sp > 0) {
             const uint32_t entry = stack[(--sp) * 64 + lane];
             const int e = (int)(entry & 0xFFFFu);
@@ -386,7 +387,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = n.c + side;
                     h.xf = cur_xf;
                 }
-            } else if ((F & F_SET) != 0 && kind == DEV_NODE_SPHERE_SET) {
+            } else if ((F & F_SET) != 0 && kind == DEV_NODE_LEAF_SET) {
                 if (hit_aabb(n.p, cur, inv, T_MIN, h.t)) pending_set = e;  // bvh_node::hit's own test, B2/bvh.h:98-99
             } else if ((F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM) {
                 medium_hit<F>(S, n, e, cur, cur_xf, tm, g, h);
@@ -401,7 +402,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             }
         }
         if constexpr ((F & F_SET) != 0) {
-            // Sphere sets are evaluated by the wave as a whole, one set at a time (the lanes of a trip are inside one
+            // Leaf sets are evaluated by the wave as a whole, one set at a time (the lanes of a trip are inside one
             // top-level object, so normally they all wait at the same set).  The subtree keeps the smallest root in
             // [t_min, closest so far] whatever order its leaves are tested in (B2/bvh.h:97-106): so does the list.
             for (uint64_t pend = ballot(pending_set >= 0); pend != 0ull;) {
@@ -409,15 +410,44 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                 const bool mine = pending_set == node;
                 const int set_index = __builtin_amdgcn_readfirstlane(S.nodes[node].a);
                 const int first_slot = __builtin_amdgcn_readfirstlane(S.nodes[node].b);
-                const SphereSetDev set = S.sets[set_index];
+                const LeafSetDev set = S.sets[set_index];
                 uint16_t* list = (uint16_t*)(stack + SET_STACK_SLOTS * 64);
                 uint32_t* rows = stack + SET_STACK_SLOTS * 64 + CAND_CAP * 32;
-                uint32_t overflowed = 0;
-                ProbeClock clk;
-                const SetHit sh = closest_hit<false>(set, cur.o, cur.d, 0.0, h.t, mine, false, list, rows, lane, overflowed, clk);
-                if (mine && sh.id >= 0) {
-                    h.t = sh.t;
-                    h.node = S.set_nodes[first_slot + sh.id];
+                int winner = -1;
+                double best_t = h.t;
+                if (set.spheres.n > 0) {
+                    uint32_t overflowed = 0;
+                    ProbeClock clk;
+                    const SetHit sh = closest_hit_with(set.spheres, cur.o, cur.d, best_t, mine, false, list, rows, lane, overflowed, clk,
+                                                       [&](int j, SetHit& best) {
+                        const int id = S.set_nodes[first_slot + j];
+                        const SceneNode n = S.nodes[id];
+                        double t;
+                        if (hit_sphere(d3{n.p[0], n.p[1], n.p[2]}, n.p[3], cur, a, T_MIN, best.t, t)) {
+                            best.t = t;
+                            best.id = j;
+                            winner = id;
+                        }
+                    });
+                    best_t = sh.t;
+                }
+                if constexpr ((F & F_RECT) != 0) {
+                    if (set.boxes.n > 0) {
+                        const int first_box = first_slot + set.spheres.n;
+                        const SetHit bh = closest_box_hit(set.boxes, cur.o, cur.d, best_t, mine, list, lane, [&](int j, SetHit& best) {
+                            const SceneNode n = S.nodes[S.set_nodes[first_box + j]];
+                            const int side = hit_box6(n.p, cur, T_MIN, best.t);
+                            if (side >= 0) {
+                                best.id = j;
+                                winner = n.c + side;
+                            }
+                        });
+                        best_t = bh.t;
+                    }
+                }
+                if (mine && winner >= 0) {
+                    h.t = best_t;
+                    h.node = winner;
                     h.xf = cur_xf;
                 }
                 if (mine) pending_set = -1;
@@ -862,7 +892,7 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
 #define RT_SCENE_WAVES_B 3
 #endif
 #ifndef RT_SCENE_WAVES_SET
-#define RT_SCENE_WAVES_SET 3
+#define RT_SCENE_WAVES_SET 2
 #endif
 constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
 constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
@@ -930,7 +960,7 @@ int scene_feature_bit_for_node(int kind) {
     case RT_NODE_ROTATE_Y: return F_XF;
     case RT_NODE_FLIP_FACE: return F_XF | F_FLIP;
     case RT_NODE_MEDIUM: return F_MEDIUM;
-    case DEV_NODE_SPHERE_SET: return F_SET;
+    case DEV_NODE_LEAF_SET: return F_SET;
     default: return 0;
     }
 }

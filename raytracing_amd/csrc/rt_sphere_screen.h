@@ -165,17 +165,18 @@ __device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3
 // Closest hit in [t_min, t_max] of one ray per lane against the whole set; id = -1 if there is none.  Must be called
 // by all 64 lanes of the wave (wave-level loops); lanes with on == false take no part in the result.
 // `list` = this wave's CAND_CAP*64 uint16 slots in LDS, `rows` = its ROW_WORDS*64 words.
-template <bool TIMED>
-__device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d, double tm, double t_max, bool on, bool exact_only,
-                                           uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
-                                           ProbeClock& pc) {
+// exact(j, h) is the double-precision test of member j: it lowers h.t and sets h.id = j if j is hit in [t_min, h.t].
+// The screening image holds, per member, a sphere that the member lies inside.
+template <class ExactFn>
+__device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, d3 d, double t_max, bool on, bool exact_only,
+                                                   uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
+                                                   ProbeClock& pc, ExactFn exact) {
     const double a = len2(d);
-    const double t_min = 0.001;  // B1/RayTracing.cpp:17
     SetHit h{t_max, -1};
 
     if (exact_only) {
         if (on) {
-            for (int j = 0; j < S.n; ++j) exact_one<TIMED>(S, j, o, d, a, tm, t_min, h);
+            for (int j = 0; j < S.n; ++j) exact(j, h);
         }
         return h;
     }
@@ -257,16 +258,27 @@ __device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d,
     const bool overflow = cnt > (uint32_t)CAND_CAP;
     const uint32_t my_n = overflow ? 0u : cnt;
     for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
-        if (i < my_n) exact_one<TIMED>(S, (int)list[i * 64 + lane], o, d, a, tm, t_min, h);
+        if (i < my_n) exact((int)list[i * 64 + lane], h);
     }
     if (ballot(overflow) != 0ull) {
         if (overflow) {  // more candidates than slots: test the whole list in double
             ++overflow_count;
-            for (int j = 0; j < S.n; ++j) exact_one<TIMED>(S, j, o, d, a, tm, t_min, h);
+            for (int j = 0; j < S.n; ++j) exact(j, h);
         }
     }
     pc.mark(SEC_EXACT);
     return h;
+}
+
+// The set's members are its spheres themselves (sphere-list kernels).
+template <bool TIMED>
+__device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d, double tm, double t_max, bool on, bool exact_only,
+                                              uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
+                                              ProbeClock& pc) {
+    const double a = len2(d);
+    const double t_min = 0.001;  // B1/RayTracing.cpp:17
+    return closest_hit_with(S, o, d, t_max, on, exact_only, list, rows, lane, overflow_count, pc,
+                            [&](int j, SetHit& h) { exact_one<TIMED>(S, j, o, d, a, tm, t_min, h); });
 }
 
 }  // namespace rtd

@@ -329,3 +329,79 @@ def test_final_scene_sphere_cube_as_a_set(monkeypatch, kat_b2):
     assert sa["rays"] == sb["rays"] and np.array_equal(a, b) and np.array_equal(ids_a, ids_b)
     rows = ob.render_rows(scene, camera_b2(k), p, 60, 62, has_time=True) / FRAC
     assert np.array_equal(a[60:62], rows)
+
+
+def box_field_world(scale=1.0):
+    """root list [ground sphere, bvh over 5 boxes of unequal heights, metal sphere]; lengths multiplied by `scale`."""
+    tex = np.zeros(2, abi.TEXTURE_DTYPE)
+    tex["kind"] = abi.RT_TEX_SOLID
+    tex["p"][0][:3] = (0.48, 0.83, 0.53)
+    tex["p"][1][:3] = (0.6, 0.5, 0.4)
+    mat = np.zeros(3, abi.MATERIAL_DTYPE)
+    mat["kind"] = [abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL]
+    mat["texture"] = [0, 1, -1]
+    mat["albedo"][2] = (0.8, 0.8, 0.9)
+    mat["param"] = [0, 0, 0.05]
+    corners = [((-2.0, 0.0, -1.0), (-1.0, 0.9, 0.0)), ((-1.0, 0.0, -1.0), (0.0, 0.4, 0.0)), ((0.0, 0.0, -1.0), (1.0, 1.3, 0.0)),
+               ((-1.0, 0.0, 0.0), (0.0, 0.7, 1.0)), ((0.0, 0.0, 0.0), (1.0, 0.2, 1.0))]
+    n_boxes = len(corners)
+    first_box = 3
+    first_side = first_box + n_boxes
+    first_bvh = first_side + 6 * n_boxes
+    nodes = np.zeros(first_bvh + n_boxes - 1, abi.NODE_DTYPE)
+    nodes["material"] = -1
+    children = [1, 2, first_bvh]
+    nodes[0]["kind"], nodes[0]["child0"], nodes[0]["child1"] = abi.RT_NODE_LIST, 0, 3
+    nodes[1]["kind"], nodes[1]["material"] = abi.RT_NODE_SPHERE, 1
+    nodes[1]["p"][:4] = (0, -1000 * scale, 0, 1000 * scale)
+    nodes[2]["kind"], nodes[2]["material"] = abi.RT_NODE_SPHERE, 2
+    nodes[2]["p"][:4] = (1.8 * scale, 0.6 * scale, 1.2 * scale, 0.6 * scale)
+    for b, (lo, hi) in enumerate(corners):
+        (x0, y0, z0), (x1, y1, z1) = np.array(lo) * scale, np.array(hi) * scale
+        i = first_box + b
+        nodes[i]["kind"], nodes[i]["child0"], nodes[i]["child1"] = abi.RT_NODE_BOX, len(children), 6
+        nodes[i]["p"][:6] = (x0, y0, z0, x1, y1, z1)
+        sides = [(abi.RT_NODE_XY_RECT, (x0, x1, y0, y1, z1)), (abi.RT_NODE_XY_RECT, (x0, x1, y0, y1, z0)),
+                 (abi.RT_NODE_XZ_RECT, (x0, x1, z0, z1, y1)), (abi.RT_NODE_XZ_RECT, (x0, x1, z0, z1, y0)),
+                 (abi.RT_NODE_YZ_RECT, (y0, y1, z0, z1, x1)), (abi.RT_NODE_YZ_RECT, (y0, y1, z0, z1, x0))]
+        for s, (kind, p) in enumerate(sides):
+            j = first_side + 6 * b + s
+            nodes[j]["kind"], nodes[j]["material"] = kind, 0
+            nodes[j]["p"][:5] = p
+            children.append(j)
+
+    def box(i):
+        n = nodes[i]
+        if n["kind"] == abi.RT_NODE_BOX:
+            return n["p"][:3].copy(), n["p"][3:6].copy()
+        lo_l, hi_l = box(n["child0"])
+        lo_r, hi_r = box(n["child1"])
+        return np.minimum(lo_l, lo_r), np.maximum(hi_l, hi_r)
+
+    # a chain-shaped tree: bvh_k = (box_k, bvh_{k+1}), the last one holds two boxes
+    for k in range(n_boxes - 2, -1, -1):
+        i = first_bvh + k
+        nodes[i]["kind"] = abi.RT_NODE_BVH
+        nodes[i]["child0"] = first_box + k
+        nodes[i]["child1"] = first_bvh + k + 1 if k < n_boxes - 2 else first_box + k + 1
+        lo, hi = box(i)
+        nodes[i]["p"][:6] = (*lo, *hi)
+    return abi.Scene(0, nodes, np.array(children, dtype=np.int32), mat, tex, np.zeros(0, abi.PERLIN_DTYPE))
+
+
+@pytest.mark.parametrize("scale,lookfrom", [(1.0, (4.0, 3.0, 5.0)), (1.0e5, (4.0e5, 3.0e5, 5.0e5)), (2.0e5, (4.0e6, 3.0e6, 5.0e6))])
+def test_box_subtrees_inside_a_graph_match_oracle(monkeypatch, scale, lookfrom):
+    """The slab screen of the boxes against the oracle; at the largest scale the camera lies outside the range the
+    float bound covers (|origin| > 1e6), so primary rays take the all-boxes-in-double path."""
+    scene = box_field_world(scale)
+    mk = lambda f: f(lookfrom, (0, 0.4 * scale, 0), (0, 1, 0), 30.0, 4.0 / 3.0, 0.0, 1.0, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(64, 48, 6, 50, seed=8)
+    want, ost = oracle_sums(scene, ocam, p)
+    want_ids = ob.first_hit(scene, ocam, 80, 60)
+    assert 2 in np.unique(want_ids)
+    for set_min in (2, 1000):
+        got, st, ids = render_with_subtree_sets(monkeypatch, scene, cam, p, set_min)
+        assert st["rays"] == ost["rays"], set_min
+        assert np.array_equal(got, want), (set_min, np.abs(got - want).max())
+        assert np.array_equal(ids, want_ids), set_min
