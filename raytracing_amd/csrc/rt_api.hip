@@ -447,33 +447,39 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
     return RT_OK;
 }
 
-// Float image of the boxes `prims` (RT_NODE_BOX node ids) for the slab screen: lower corners rounded down, upper
-// corners rounded up, padded to whole screening groups.
-static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, BoxSetDev& B) {
+// Float image of the boxes `prims` (RT_NODE_BOX node ids) for the slab screen: centre and half-width per axis, the
+// half-width widened by the margin derived in rt_box_screen.h for rays whose origin lies within `cover` of the
+// coordinate origin; padded to whole screening groups.  cover must be >= 0 and, like the coordinates, <= 8e6.
+static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, double cover, BoxSetDev& B) {
     const int n = (int)prims.size();
     const int n_groups = std::max(1, (n + SCREEN_GROUP - 1) / SCREEN_GROUP);
     std::vector<BoxPair> screen((size_t)n_groups * (SCREEN_GROUP / 2));
     std::memset(screen.data(), 0, screen.size() * sizeof(BoxPair));
     double coord_max = 0.0;
+    for (int id : prims)
+        for (int k = 0; k < 6; ++k) coord_max = std::fmax(coord_max, std::fabs(sc->nodes[id].p[k]));
+    const double margin = 0x1p-21 * (coord_max + cover);
     for (int i = 0; i < n; ++i) {
         const rt_node& nd = sc->nodes[prims[(size_t)i]];
         BoxPair& bp = screen[(size_t)i / 2];
         for (int k = 0; k < 3; ++k) {
             // the corners as given are box_min / box_max (B2/box.h:28-30); order them in case they are not
             const double lo = std::fmin(nd.p[k], nd.p[3 + k]), hi = std::fmax(nd.p[k], nd.p[3 + k]);
-            float lf = (float)lo, hf = (float)hi;
-            if ((double)lf > lo) lf = std::nextafterf(lf, -INFINITY);
-            if ((double)hf < hi) hf = std::nextafterf(hf, INFINITY);
-            bp.lo[k][i & 1] = lf;
-            bp.hi[k][i & 1] = hf;
-            coord_max = std::fmax(coord_max, std::fmax(std::fabs(lo), std::fabs(hi)));
+            const double mid = 0.5 * (lo + hi);
+            const float mid_f = (float)mid;
+            const double hw = (0.5 * (hi - lo) + std::fabs(mid - (double)mid_f) + margin) * (1.0 + 1e-12);
+            float hw_f = (float)hw;
+            if ((double)hw_f < hw) hw_f = std::nextafterf(hw_f, INFINITY);
+            bp.mid[k][i & 1] = mid_f;
+            bp.hw[k][i & 1] = hw_f;
         }
     }
     B = BoxSetDev{};
     int rc;
     if ((rc = to_device(ctx, screen, &B.screen)) != RT_OK) return rc;
     B.n = n;
-    B.coord_max = std::nextafterf((float)coord_max, INFINITY);
+    B.cover = (float)cover;
+    if ((double)B.cover > cover) B.cover = std::nextafterf(B.cover, 0.0f);  // never claim more than the margin covers
     return RT_OK;
 }
 
@@ -596,6 +602,28 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     // BVH subtrees of static spheres and boxes directly under a top-level object's instance chain become leaf sets
     std::vector<LeafSetDev> sets;
     std::vector<int32_t> set_nodes;
+    // eight times the largest coordinate that appears in the world: room for instance offsets and for a camera
+    // outside the objects; rays that start farther out skip the boxes' float screen
+    double world_extent = 0.0;
+    for (int i = 0; i < sc->n_nodes; ++i) {
+        const rt_node& n = sc->nodes[i];
+        int used = 0;
+        switch (n.kind) {
+        case RT_NODE_SPHERE: used = 4; break;
+        case RT_NODE_MOVING_SPHERE: used = 6; break;
+        case RT_NODE_XY_RECT:
+        case RT_NODE_XZ_RECT:
+        case RT_NODE_YZ_RECT: used = 5; break;
+        case RT_NODE_BOX:
+        case RT_NODE_BVH: used = 6; break;
+        case RT_NODE_TRANSLATE: used = 3; break;
+        default: break;
+        }
+        for (int k = 0; k < used; ++k)
+            if (std::isfinite(n.p[k])) world_extent = std::fmax(world_extent, std::fabs(n.p[k]));
+        if (n.kind == RT_NODE_SPHERE) world_extent = std::fmax(world_extent, std::fabs(n.p[0]) + std::fabs(n.p[3]));
+    }
+    const double cover = std::fmin(8.0 * world_extent, 8e6);
     {
         const rt_node& root = sc->nodes[sc->root];
         for (int i = 0; i < root.child1 && ctx->subtree_set_min <= ctx->subtree_set_max; ++i) {
@@ -614,11 +642,11 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
                 if (leaf.kind == RT_NODE_BOX)
                     for (int k = 0; k < 6; ++k) coord_max = std::fmax(coord_max, std::fabs(leaf.p[k]));
             }
-            if (!(coord_max <= 1e6)) continue;  // the slab screen's bound assumes it (also rejects NaN)
+            if (!(coord_max <= 8e6)) continue;  // the slab screen's bound assumes it (also rejects NaN)
             LeafSetDev sd{};
             double lo, hi;
             int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, sd.spheres, lo, hi);
-            if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, sd.boxes);
+            if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, cover, sd.boxes);
             if (rc != RT_OK) return rc;
             nodes[(size_t)idx].kind = DEV_NODE_LEAF_SET;  // p keeps the subtree's box
             nodes[(size_t)idx].a = (int32_t)sets.size();

@@ -10,38 +10,35 @@ namespace rtd {
 // ---------------------------------------------------------------- screening pass
 //
 // Every side of a box lies in the closed box [lo, hi] (B2/box.h:31-38), so a hit at t in [t_min, t_max] implies that
-// t lies in all three slab intervals  [ (lo_k - o_k)/d_k , (hi_k - o_k)/d_k ]  (ends swapped for d_k < 0) and that
-// t >= 0.  The screen evaluates, in float,
-//     a_k = lo_k * inv_k + c_lo_k,   b_k = hi_k * inv_k + c_hi_k,        inv_k = 1/d_k
-//     near = max(min(a_k, b_k), 0),  far = min(max(a_k, b_k)),           candidate iff near <= far
-// with c_lo_k = -o_k inv_k - s mu_k, c_hi_k = -o_k inv_k + s mu_k, s = sign(inv_k): each slab interval is widened by
-// mu_k at both ends.  The float image rounds lo down and hi up (which only widens the intervals); rounding inv_k and
-// c to float and the fma itself perturb a_k and b_k by less than 2 eps (B + |o_k|) |inv_k|, eps = 2^-24, B = the
-// largest |coordinate| of the set; mu_k = 2^-21 (B + |o_k|) |inv_k| is four times that.  So every float interval
-// contains the exact one, and a box the reference hits is always a candidate.  Rays the bound does not cover
-// (|o_k| > 1e6, |d_k| outside [1e-30, 1e30], non-finite) test every box in double instead; with them excluded and
-// B <= 1e6 (checked at upload) no product overflows, so no NaN can arise.
+// t >= 0 and that t lies in all three slab intervals, which have centre (mid_k - o_k)/d_k and half-width
+// hw_k/|d_k| (mid = (lo+hi)/2, hw = (hi-lo)/2).  The screen evaluates, in float and on box pairs,
+//     tc_k   = mid_k * inv_k + c_k                 inv_k = 1/d_k,  c_k = -o_k inv_k
+//     near_k = tc_k - hw'_k |inv_k|,  far_k = tc_k + hw'_k |inv_k|
+//     candidate iff  max_k near_k <= min_k far_k  and  min_k far_k >= 0.
+// Rounding mid, inv and c to float and the three fused operations perturb near_k and far_k by less than
+// 5 eps (B + |o_k|) |inv_k| (eps = 2^-24, B = largest |coordinate| of the set).  The image's half-widths are
+// hw' = hw + |mid - float(mid)| + 2^-21 (B + O), rounded up: for rays with |o_k| <= O every float interval contains the
+// exact one (8 eps against 5 eps), so a box the reference hits is always a candidate.  O ("cover") is eight times
+// the largest coordinate of the whole world; rays the bound does not cover (|o_k| > O, |d_k| outside [1e-30, 1e30],
+// non-finite) test every box in double instead.  With those excluded and B, O <= 8e6 (checked at upload) no product
+// overflows, so no NaN arises.
 struct BoxScreenRay {
-    f2 inv[3], c_lo[3], c_hi[3];
+    f2 inv[3], ainv[3], c[3];
     bool covered;
 };
 
-__device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, float coord_max) {
+__device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, float cover) {
     BoxScreenRay s;
     s.covered = true;
     const double ok[3] = {o.x, o.y, o.z}, dk[3] = {d.x, d.y, d.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double ad = fabs(dk[k]), ao = fabs(ok[k]);
-        if (!(ad >= 1e-30 && ad <= 1e30 && ao <= 1e6)) s.covered = false;
+        if (!(ad >= 1e-30 && ad <= 1e30 && ao <= (double)cover)) s.covered = false;
         const double inv = 1.0 / dk[k];
-        const double base = -ok[k] * inv;
-        const double mu = 0x1p-21 * ((double)coord_max + ao) * fabs(inv);
-        const double lo_c = inv >= 0 ? base - mu : base + mu;
-        const double hi_c = inv >= 0 ? base + mu : base - mu;
         s.inv[k] = splat(inv);
-        s.c_lo[k] = splat(lo_c);
-        s.c_hi[k] = splat(hi_c);
+        s.ainv[k] = f2{fabsf(s.inv[k].x), fabsf(s.inv[k].x)};
+        s.c[k] = splat(-ok[k] * inv);
     }
     return s;
 }
@@ -50,17 +47,20 @@ typedef __attribute__((address_space(4))) BoxPair ConstBoxPair;
 
 // Screens the two boxes of *p; appends their sign bits (first box first; 1 = no candidate) to mask.
 __device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const ConstBoxPair* p, uint32_t mask) {
-    const f2 ax = pk_fma(f2{p->lo[0][0], p->lo[0][1]}, r.inv[0], r.c_lo[0]);
-    const f2 bx = pk_fma(f2{p->hi[0][0], p->hi[0][1]}, r.inv[0], r.c_hi[0]);
-    const f2 ay = pk_fma(f2{p->lo[1][0], p->lo[1][1]}, r.inv[1], r.c_lo[1]);
-    const f2 by = pk_fma(f2{p->hi[1][0], p->hi[1][1]}, r.inv[1], r.c_hi[1]);
-    const f2 az = pk_fma(f2{p->lo[2][0], p->lo[2][1]}, r.inv[2], r.c_lo[2]);
-    const f2 bz = pk_fma(f2{p->hi[2][0], p->hi[2][1]}, r.inv[2], r.c_hi[2]);
+    f2 near_t[3], far_t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const f2 hw{p->hw[k][0], p->hw[k][1]};
+        const f2 tc = pk_fma(f2{p->mid[k][0], p->mid[k][1]}, r.inv[k], r.c[k]);
+        near_t[k] = pk_fma(hw, -r.ainv[k], tc);
+        far_t[k] = pk_fma(hw, r.ainv[k], tc);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const float near_t = fmaxf(fmaxf(fminf(ax[h], bx[h]), fminf(ay[h], by[h])), fmaxf(fminf(az[h], bz[h]), 0.0f));
-        const float far_t = fminf(fminf(fmaxf(ax[h], bx[h]), fmaxf(ay[h], by[h])), fmaxf(az[h], bz[h]));
-        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(far_t - near_t), 31);
+        const float far_all = fminf(fminf(far_t[0][h], far_t[1][h]), far_t[2][h]);
+        const float near_all = fmaxf(fmaxf(near_t[0][h], near_t[1][h]), near_t[2][h]);
+        const float q = fminf(far_all - near_all, far_all);  // negative: the intervals do not meet, or the box is behind
+        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q), 31);
     }
     return mask;
 }
@@ -71,7 +71,7 @@ template <class ExactFn>
 __device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d, double t_max, bool on, uint16_t* list,
                                                   int lane, ExactFn exact) {
     SetHit h{t_max, -1};
-    const BoxScreenRay sr = box_screen_prepare(o, d, B.coord_max);
+    const BoxScreenRay sr = box_screen_prepare(o, d, B.cover);
     uint32_t cnt = (on && !sr.covered) ? (uint32_t)CAND_CAP + 1u : 0u;
     const ConstBoxPair* bp = (const ConstBoxPair*)B.screen;
     const int n_groups = (B.n + SCREEN_GROUP - 1) / SCREEN_GROUP;

@@ -53,12 +53,12 @@ struct SphereSetDev {
 };
 // Screening image of axis-aligned boxes: two boxes interleaved component by component, like SpherePair.
 struct BoxPair {
-    float lo[3][2];  // rounded down
-    float hi[3][2];  // rounded up
+    float mid[3][2];  // centre per axis
+    float hw[3][2];   // half-width per axis, widened by the screen's error margin (rt_box_screen.h), rounded up
 };
 struct BoxSetDev {
     int32_t n;
-    float coord_max;  // largest |coordinate| of the boxes
+    float cover;            // the margin holds for rays whose origin coordinates are at most this in magnitude
     const BoxPair* screen;  // padded to whole groups of SCREEN_GROUP boxes
 };
 // The leaves of a DEV_NODE_LEAF_SET node: spheres, then boxes.

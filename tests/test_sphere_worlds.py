@@ -389,12 +389,13 @@ def box_field_world(scale=1.0):
     return abi.Scene(0, nodes, np.array(children, dtype=np.int32), mat, tex, np.zeros(0, abi.PERLIN_DTYPE))
 
 
-@pytest.mark.parametrize("scale,lookfrom", [(1.0, (4.0, 3.0, 5.0)), (1.0e5, (4.0e5, 3.0e5, 5.0e5)), (2.0e5, (4.0e6, 3.0e6, 5.0e6))])
-def test_box_subtrees_inside_a_graph_match_oracle(monkeypatch, scale, lookfrom):
-    """The slab screen of the boxes against the oracle; at the largest scale the camera lies outside the range the
-    float bound covers (|origin| > 1e6), so primary rays take the all-boxes-in-double path."""
+@pytest.mark.parametrize("scale,lookfrom,vfov", [(1.0, (4.0, 3.0, 5.0), 30.0), (1.0e5, (4.0e5, 3.0e5, 5.0e5), 30.0),
+                                                 (2.0e5, (4.0e7, 3.0e7, 5.0e7), 1.0)])
+def test_box_subtrees_inside_a_graph_match_oracle(monkeypatch, scale, lookfrom, vfov):
+    """The slab screen of the boxes against the oracle; in the last case the camera lies outside the range the
+    float bound covers (|origin| > 8e6), so primary rays take the all-boxes-in-double path."""
     scene = box_field_world(scale)
-    mk = lambda f: f(lookfrom, (0, 0.4 * scale, 0), (0, 1, 0), 30.0, 4.0 / 3.0, 0.0, 1.0, 0.0, 1.0)
+    mk = lambda f: f(lookfrom, (0, 0.4 * scale, 0), (0, 1, 0), vfov, 4.0 / 3.0, 0.0, 1.0, 0.0, 1.0)
     cam, ocam = mk(lib.camera), mk(ob.camera)
     p = abi.render_params(64, 48, 6, 50, seed=8)
     want, ost = oracle_sums(scene, ocam, p)
