@@ -161,10 +161,8 @@ struct SceneDev {
     int32_t features;  // F_* bits of rt_kernels_scene.hip the world needs
     double background[3];
 };
-constexpr int STACK_CAP = 40;   // traversal stack slots per lane (uint32 each, in LDS)
-// While a sphere set is evaluated, the slots above this one hold its candidate lists: a top-level object that contains
-// a set may not need more stack than this (instances chains are at most XF_DEPTH_CAP deep, so it never does).
-constexpr int SET_STACK_SLOTS = 7;
+constexpr int STACK_CAP = 40;   // traversal stack slots per lane (uint32 each, in LDS); a leaf set, evaluated while the
+                                // stack is empty, keeps its candidate lists in the same memory
 constexpr int XF_DEPTH_CAP = 4;  // nested translate / rotate_y levels
 
 struct SceneRenderArgs {

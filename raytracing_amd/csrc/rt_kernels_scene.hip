@@ -49,7 +49,7 @@ enum : int {
     F_SET = 512,     // BVH subtrees of spheres / boxes evaluated as leaf sets (DEV_NODE_LEAF_SET); not part of F_ALL
     F_EVERY = F_ALL | F_FLIP | F_SET,
 };
-static_assert(SET_STACK_SLOTS * 64 + CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "candidate lists of a sphere set overlay the upper stack slots");
+static_assert(CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "the candidate lists of a leaf set use the stack's memory (a set is evaluated while the stack is empty)");
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
 
 struct Ray {
@@ -325,8 +325,114 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
     const int top_first = __builtin_amdgcn_readfirstlane(S.nodes[S.root].a);
     const int top_count = __builtin_amdgcn_readfirstlane(S.nodes[S.root].b);
     for (int top = 0; top < top_count; ++top) {
+    const int top_node = __builtin_amdgcn_readfirstlane(S.children[top_first + top]);
+    {   // An object of the world that is a primitive, a box, a medium or a leaf set, by itself or under a chain of
+        // instances, is the same node for every lane: its data come through scalar loads and nothing goes through
+        // the stack.
+        int node = top_node, chain = 0;
+        int kind = __builtin_amdgcn_readfirstlane(S.nodes[node].kind);
+        if constexpr ((F & F_XF) != 0) {
+            while (chain < XF_DEPTH_CAP && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y ||
+                                            ((F & F_FLIP) != 0 && kind == RT_NODE_FLIP_FACE))) {
+                node = __builtin_amdgcn_readfirstlane(S.nodes[node].a);
+                kind = __builtin_amdgcn_readfirstlane(S.nodes[node].kind);
+                ++chain;
+            }
+        }
+        const bool plain = kind >= RT_NODE_SPHERE && kind <= RT_NODE_YZ_RECT;
+        const bool box6 = (F & F_RECT) != 0 && kind == DEV_NODE_BOX6;
+        const bool medium = (F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM;
+        const bool leaf_set = (F & F_SET) != 0 && kind == DEV_NODE_LEAF_SET;
+        if (plain || box6 || medium || leaf_set) {
+            Ray loc = w;
+            int loc_xf = -1;
+            if constexpr ((F & F_XF) != 0) {
+                int x = top_node;
+                for (int i = 0; i < chain; ++i) {  // the rays handed down by translate::hit / rotate_y::hit, outermost first
+                    const SceneNode xn = S.nodes[x];
+                    if (!((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE)) loc = xf_apply(xn, loc);
+                    loc_xf = x;
+                    x = xn.a;
+                }
+            }
+            const SceneNode n = S.nodes[node];
+            if (plain) {
+                double t;
+                if (on && prim_hit<F>(S, n, loc, len2(loc.d), tm, T_MIN, h.t, t)) {
+                    h.t = t;
+                    h.node = node;
+                    h.xf = loc_xf;
+                }
+            } else if (box6) {
+                if constexpr ((F & F_RECT) != 0) {
+                    const int side = on ? hit_box6(n.p, loc, T_MIN, h.t) : -1;
+                    if (side >= 0) {
+                        h.node = n.c + side;
+                        h.xf = loc_xf;
+                    }
+                }
+            } else if (medium) {
+                if constexpr ((F & F_MEDIUM) != 0) {
+                    if (on) medium_hit<F>(S, n, node, loc, loc_xf, tm, g, h);
+                }
+            } else {
+                if constexpr ((F & F_SET) != 0) {
+                    // bvh_node::hit's own box test (B2/bvh.h:98-99), then the subtree's leaves as a flat set: the
+                    // subtree keeps the smallest root in [t_min, closest so far] whatever order its leaves are tested
+                    // in (B2/bvh.h:97-106), and so does the list
+                    const d3 loc_inv{1.0f / loc.d.x, 1.0f / loc.d.y, 1.0f / loc.d.z};
+                    const bool mine = on && hit_aabb(n.p, loc, loc_inv, T_MIN, h.t);
+                    if (ballot(mine) != 0ull) {
+                        const LeafSetDev set = S.sets[n.a];
+                        const int first_slot = n.b;
+                        const double loc_a = len2(loc.d);
+                        uint16_t* list = (uint16_t*)stack;
+                        uint32_t* rows = stack + CAND_CAP * 32;
+                        int winner = -1;
+                        double best_t = h.t;
+                        if (set.spheres.n > 0) {
+                            uint32_t overflowed = 0;
+                            ProbeClock clk;
+                            const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, false, list, rows, lane, overflowed, clk,
+                                                               [&](int j, SetHit& best) {
+                                const int id = S.set_nodes[first_slot + j];
+                                const SceneNode sn = S.nodes[id];
+                                double t;
+                                if (hit_sphere(d3{sn.p[0], sn.p[1], sn.p[2]}, sn.p[3], loc, loc_a, T_MIN, best.t, t)) {
+                                    best.t = t;
+                                    best.id = j;
+                                    winner = id;
+                                }
+                            });
+                            best_t = sh.t;
+                        }
+                        if constexpr ((F & F_RECT) != 0) {
+                            if (set.boxes.n > 0) {
+                                const int first_box = first_slot + set.spheres.n;
+                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, list, lane, [&](int j, SetHit& best) {
+                                    const SceneNode bn = S.nodes[S.set_nodes[first_box + j]];
+                                    const int side = hit_box6(bn.p, loc, T_MIN, best.t);
+                                    if (side >= 0) {
+                                        best.id = j;
+                                        winner = bn.c + side;
+                                    }
+                                });
+                                best_t = bh.t;
+                            }
+                        }
+                        if (mine && winner >= 0) {
+                            h.t = best_t;
+                            h.node = winner;
+                            h.xf = loc_xf;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+    }
     int sp = 0;
-    if (on) stack[(sp++) * 64 + lane] = (uint32_t)S.children[top_first + top];
+    if (on) stack[(sp++) * 64 + lane] = (uint32_t)top_node;
 
     while (ballot(sp > 0) != 0ull) {
 #ifdef RT_SCENE_PROBE
@@ -335,12 +441,10 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             atomicAdd(&g_probe_total[13], (unsigned long long)__popcll(ballot(sp > 0)));
         }
 #endif
-        int pending_set = -1;  // leaf-set node this lane has reached (its box is hit); evaluated by the whole wave below
         if (sp > 0) {
             const uint32_t entry = stack[(--sp) * 64 + lane];
             const int e = (int)(entry & 0xFFFFu);
             const uint32_t tag = entry >> 16;
-            bool leaving = false;
             if constexpr ((F & F_XF) != 0) {
                 if (tag >= END_XF_TRANSLATE) {  // leave instance node e: back to the ray of the level above
                     cur_xf = S.parent_xf[e];
@@ -349,11 +453,9 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         inv = d3{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
                         a = len2(cur.d);
                     }
-                    if constexpr ((F & F_SET) == 0) continue;
-                    leaving = true;  // with sets, every lane must reach the wave-level part of the trip
+                    continue;
                 }
             }
-            if (!leaving) {
             const SceneNode n = S.nodes[e];
             const int kind = n.kind;
 #ifdef RT_SCENE_PROBE
@@ -387,8 +489,6 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = n.c + side;
                     h.xf = cur_xf;
                 }
-            } else if ((F & F_SET) != 0 && kind == DEV_NODE_LEAF_SET) {
-                if (hit_aabb(n.p, cur, inv, T_MIN, h.t)) pending_set = e;  // bvh_node::hit's own test, B2/bvh.h:98-99
             } else if ((F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM) {
                 medium_hit<F>(S, n, e, cur, cur_xf, tm, g, h);
             } else {
@@ -398,60 +498,6 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = e;
                     h.xf = cur_xf;
                 }
-            }
-            }
-        }
-        if constexpr ((F & F_SET) != 0) {
-            // Leaf sets are evaluated by the wave as a whole, one set at a time (the lanes of a trip are inside one
-            // top-level object, so normally they all wait at the same set).  The subtree keeps the smallest root in
-            // [t_min, closest so far] whatever order its leaves are tested in (B2/bvh.h:97-106): so does the list.
-            for (uint64_t pend = ballot(pending_set >= 0); pend != 0ull;) {
-                const int node = __builtin_amdgcn_readlane(pending_set, __builtin_ctzll(pend));
-                const bool mine = pending_set == node;
-                const int set_index = __builtin_amdgcn_readfirstlane(S.nodes[node].a);
-                const int first_slot = __builtin_amdgcn_readfirstlane(S.nodes[node].b);
-                const LeafSetDev set = S.sets[set_index];
-                uint16_t* list = (uint16_t*)(stack + SET_STACK_SLOTS * 64);
-                uint32_t* rows = stack + SET_STACK_SLOTS * 64 + CAND_CAP * 32;
-                int winner = -1;
-                double best_t = h.t;
-                if (set.spheres.n > 0) {
-                    uint32_t overflowed = 0;
-                    ProbeClock clk;
-                    const SetHit sh = closest_hit_with(set.spheres, cur.o, cur.d, best_t, mine, false, list, rows, lane, overflowed, clk,
-                                                       [&](int j, SetHit& best) {
-                        const int id = S.set_nodes[first_slot + j];
-                        const SceneNode n = S.nodes[id];
-                        double t;
-                        if (hit_sphere(d3{n.p[0], n.p[1], n.p[2]}, n.p[3], cur, a, T_MIN, best.t, t)) {
-                            best.t = t;
-                            best.id = j;
-                            winner = id;
-                        }
-                    });
-                    best_t = sh.t;
-                }
-                if constexpr ((F & F_RECT) != 0) {
-                    if (set.boxes.n > 0) {
-                        const int first_box = first_slot + set.spheres.n;
-                        const SetHit bh = closest_box_hit(set.boxes, cur.o, cur.d, best_t, mine, list, lane, [&](int j, SetHit& best) {
-                            const SceneNode n = S.nodes[S.set_nodes[first_box + j]];
-                            const int side = hit_box6(n.p, cur, T_MIN, best.t);
-                            if (side >= 0) {
-                                best.id = j;
-                                winner = n.c + side;
-                            }
-                        });
-                        best_t = bh.t;
-                    }
-                }
-                if (mine && winner >= 0) {
-                    h.t = best_t;
-                    h.node = winner;
-                    h.xf = cur_xf;
-                }
-                if (mine) pending_set = -1;
-                pend &= ~ballot(mine);
             }
         }
     }
