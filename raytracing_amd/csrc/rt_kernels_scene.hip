@@ -626,8 +626,7 @@ __device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& 
     for (int level = 0; level < 4; ++level) {
         const TextureDev t = S.textures[ti];
         if ((F & F_CHECKER) != 0 && t.kind == RT_TEX_CHECKER) {
-            const double sines = sin(10 * s.p.x) * sin(10 * s.p.y) * sin(10 * s.p.z);
-            ti = sines < 0 ? t.b : t.a;
+            ti = checker_sines_negative(s.p) ? t.b : t.a;
             continue;
         }
         if (t.kind == RT_TEX_SOLID) return d3{t.p[0], t.p[1], t.p[2]};

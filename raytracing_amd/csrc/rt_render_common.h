@@ -70,6 +70,26 @@ __device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  
     return r0 + (1 - r0) * (x2 * x2 * x);  // pow(x, 5) by multiplication (<= 2 ulp from libm pow)
 }
 
+// checker_texture::value (B2/texture.h:46-52) needs only the SIGN of sin(10 x) sin(10 y) sin(10 z).  The sign of
+// sin(x) is that of (-1)^k r with k = rint(x / pi), r = x - k pi in [-pi/2, pi/2]; r comes from one fused
+// multiply-add against the leading 53 bits of pi, whose neglected tail moves it by less than |k| 1.3e-16 <= 4.2e-9
+// for |x| < 1e8.  When |r| > 1e-8 its sign is therefore certain (a correctly signed libm sin, as the reference's and
+// the device's are, gives the same); closer to a multiple of pi -- about one argument in 10^8 -- and for huge or
+// non-finite arguments sin() itself is evaluated.  Returns -1, 0 or +1 (0: the product is +-0 or NaN, never "< 0").
+__device__ __noinline__ int sin_sign_by_libm(double x) {  // out of line: one copy, and its registers are not the caller's
+    const double s = sin(x);
+    return s < 0 ? -1 : (s > 0 ? 1 : 0);
+}
+__device__ __forceinline__ int sin_sign(double x) {
+    const double k = rint(x * 0.318309886183790671537767526745);
+    const double r = fma(-k, 3.141592653589793116, x);
+    if (fabs(x) < 1e8 && fabs(r) > 1e-8) return (((long long)k & 1ll) != 0) == (r < 0) ? 1 : -1;
+    return sin_sign_by_libm(x);
+}
+__device__ __forceinline__ bool checker_sines_negative(d3 p) {
+    return sin_sign(10 * p.x) * sin_sign(10 * p.y) * sin_sign(10 * p.z) < 0;
+}
+
 __device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
     __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -84,3 +84,37 @@ def test_error_strings():
     for code in range(1, 8):
         assert L.rt_error_string(code) not in (b"ok", b"unknown error code")
     assert L.rt_error_string(99) == b"unknown error code"
+
+
+def test_checker_sign_rule_matches_libm():
+    """The kernels take the sign of sin(10 x) from k = rint(x / pi), r = fma(-k, pi_hi, x) when |r| > 1e-8 and |x| < 1e8
+    (rt_render_common.h: sin_sign) instead of evaluating sin().  The rule restated with exact rational arithmetic for
+    the fused multiply-add, against the sign of libm's sin: random arguments, and arguments a few ulps to a few
+    1e-8 away from multiples of pi, where the rule is closest to its limit."""
+    import math
+    from fractions import Fraction
+    PI_HI = 3.141592653589793116
+    INV_PI = 0.318309886183790671537767526745
+
+    def rule(x):
+        k = float(np.rint(x * INV_PI))
+        r = float(Fraction(x) - Fraction(k) * Fraction(PI_HI))  # one rounding, like fma
+        if abs(x) < 1e8 and abs(r) > 1e-8:
+            return 1 if ((int(k) & 1) != 0) == (r < 0) else -1
+        return None  # the kernels call sin() here
+
+    rng = np.random.default_rng(5)
+    xs = list(rng.uniform(-2.0e4, 2.0e4, 4000)) + list(rng.uniform(-9.9e7, 9.9e7, 2000))
+    for k in list(range(-40, 41)) + [1000, 31831, 3183098, 31830988]:
+        base = k * math.pi
+        for d in (0.0, 1.1e-8, -1.1e-8, 3e-8, -3e-8, 1e-6, -1e-6, 1.5, -1.5, 1.5707963, -1.5707963):
+            xs.append(base + d)
+    decided = 0
+    for x in xs:
+        got = rule(float(x))
+        if got is None:
+            continue
+        decided += 1
+        s = math.sin(float(x))
+        assert s != 0.0 and got == (1 if s > 0 else -1), (x, got, s)
+    assert decided > 0.95 * len(xs)
