@@ -47,7 +47,9 @@ enum {
 enum {
     RT_NODE_SPHERE = 1,        /* B1/sphere.h:9-21      p[0..2]=center p[3]=radius (may be <0)        */
     RT_NODE_MOVING_SPHERE = 2, /* B2/moving_sphere.h:8-25 p[0..2]=center0 p[3..5]=center1
-                                                         p[6]=time0 p[7]=time1 p[8]=radius            */
+                                                         p[6]=time0 p[7]=time1 p[8]=radius.  Its hits, and a
+                                                         medium's, carry u = v = 0 (the reference leaves the
+                                                         record's u,v indeterminate there)             */
     RT_NODE_XY_RECT = 3,       /* B2/aarect.h:7-26      p[0]=x0 p[1]=x1 p[2]=y0 p[3]=y1 p[4]=k        */
     RT_NODE_XZ_RECT = 4,       /* B2/aarect.h:49-68     p[0]=x0 p[1]=x1 p[2]=z0 p[3]=z1 p[4]=k        */
     RT_NODE_YZ_RECT = 5,       /* B2/aarect.h:91-110    p[0]=y0 p[1]=y1 p[2]=z0 p[3]=z1 p[4]=k        */

@@ -275,11 +275,16 @@ static int hit_node(hit_ctx* cx, int idx, const ray_t* r, double t_min, double t
     case RT_NODE_SPHERE:
         return hit_sphere_at(V(n->p[0], n->p[1], n->p[2]), n->p[3], n->material, s->n_textures > 0, r, t_min,
                              t_max, rec);
-    case RT_NODE_MOVING_SPHERE: { /* B2/moving_sphere.h:27-57; u,v are left as they were */
+    case RT_NODE_MOVING_SPHERE: { /* B2/moving_sphere.h:27-57.  The reference leaves rec.u, rec.v as they were:
+                                   * indeterminate for a first hit, stale after another object's.  No reference
+                                   * world reads them (its moving spheres have solid colours); pinned to 0 here
+                                   * and in the kernels so that such worlds are well defined. */
         v3 c0 = V(n->p[0], n->p[1], n->p[2]), c1 = V(n->p[3], n->p[4], n->p[5]);
         double time0 = n->p[6], time1 = n->p[7];
         v3 center = vadd(c0, vscale((r->tm - time0) / (time1 - time0), vsub(c1, c0)));
-        return hit_sphere_at(center, n->p[8], n->material, 0, r, t_min, t_max, rec);
+        if (!hit_sphere_at(center, n->p[8], n->material, 0, r, t_min, t_max, rec)) return 0;
+        rec->u = rec->v = 0.0;
+        return 1;
     }
     case RT_NODE_XY_RECT: return hit_rect(n, 2, 0, 1, r, t_min, t_max, rec);
     case RT_NODE_XZ_RECT: return hit_rect(n, 1, 0, 2, r, t_min, t_max, rec);
@@ -344,6 +349,7 @@ static int hit_node(hit_ctx* cx, int idx, const ray_t* r, double t_min, double t
         rec->normal = V(1, 0, 0);
         rec->front_face = 1;
         rec->mat = n->material;
+        rec->u = rec->v = 0.0; /* left as they were by the reference, like moving_sphere: pinned to 0 */
         return 1;
     }
     default:

@@ -1,0 +1,199 @@
+"""Randomly generated worlds through the C ABI against the oracle, bit for bit: every node kind of books 1 and 2 in
+random arrangements (top-level primitives, checker / Perlin / image textures, instance chains, boxes, BVH subtrees of spheres and boxes -- evaluated as
+leaf sets when RT_SUBTREE_SET_MIN allows --, lists inside the graph, media), random materials and both sky modes."""
+import math
+
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+
+
+class WorldBuilder:
+    def __init__(self, rng):
+        self.rng = rng
+        self.nodes = []
+        self.children = []
+        self.tex = [(abi.RT_TEX_SOLID, -1, -1, (0.8, 0.8, 0.8, 0.0))]
+        self.mat = []
+        # one Perlin table (B2/perlin.h:10-21: unit vectors and three permutations) and one small image
+        self.perlin = np.zeros(1, abi.PERLIN_DTYPE)
+        v = rng.uniform(-1, 1, (256, 3))
+        self.perlin["ranvec"][0] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        for name in ("perm_x", "perm_y", "perm_z"):
+            self.perlin[name][0] = rng.permutation(256)
+        self.image = rng.integers(0, 256, (9, 16, 3), dtype=np.uint8)
+
+    # ---- materials
+    def solid(self, rgb):
+        self.tex.append((abi.RT_TEX_SOLID, -1, -1, (*rgb, 0.0)))
+        return len(self.tex) - 1
+
+    def material(self, allow_light=True):
+        r = self.rng
+        kind = r.choice(["lambert", "checker", "noise", "image", "metal", "glass"] + (["light"] if allow_light else []))
+        if kind == "lambert":
+            self.mat.append((abi.RT_MAT_LAMBERTIAN, self.solid(r.uniform(0.1, 0.9, 3)), (0, 0, 0), 0.0))
+        elif kind == "checker":
+            a, b = self.solid(r.uniform(0.1, 0.9, 3)), self.solid(r.uniform(0.1, 0.9, 3))
+            self.tex.append((abi.RT_TEX_CHECKER, a, b, (0, 0, 0, 0)))
+            self.mat.append((abi.RT_MAT_LAMBERTIAN, len(self.tex) - 1, (0, 0, 0), 0.0))
+        elif kind == "noise":
+            self.tex.append((abi.RT_TEX_NOISE, 0, -1, (float(r.uniform(1, 6)), 0, 0, 0)))
+            self.mat.append((abi.RT_MAT_LAMBERTIAN, len(self.tex) - 1, (0, 0, 0), 0.0))
+        elif kind == "image":
+            self.tex.append((abi.RT_TEX_IMAGE, 0, -1, (0, 0, 0, 0)))
+            self.mat.append((abi.RT_MAT_LAMBERTIAN, len(self.tex) - 1, (0, 0, 0), 0.0))
+        elif kind == "metal":
+            self.mat.append((abi.RT_MAT_METAL, -1, tuple(r.uniform(0.5, 1.0, 3)), float(r.uniform(0, 0.5))))
+        elif kind == "glass":
+            self.mat.append((abi.RT_MAT_DIELECTRIC, -1, (0, 0, 0), 1.5))
+        else:
+            self.mat.append((abi.RT_MAT_DIFFUSE_LIGHT, self.solid(r.uniform(1.0, 4.0, 3)), (0, 0, 0), 0.0))
+        return len(self.mat) - 1
+
+    # ---- nodes; every method returns (node id, (lo, hi) bounding box in the node's own frame)
+    def node(self, kind, material=-1, child0=0, child1=0, p=()):
+        q = np.zeros(12)
+        q[:len(p)] = p
+        self.nodes.append((kind, material, child0, child1, q))
+        return len(self.nodes) - 1
+
+    def sphere(self, c, r):
+        c = np.asarray(c, float)
+        return self.node(abi.RT_NODE_SPHERE, self.material(), p=(*c, r)), (c - r, c + r)
+
+    def moving_sphere(self, c0, c1, r):
+        c0, c1 = np.asarray(c0, float), np.asarray(c1, float)
+        i = self.node(abi.RT_NODE_MOVING_SPHERE, self.material(), p=(*c0, *c1, 0.0, 1.0, r))
+        a0 = c0 + ((0.0 - 0.0) / (1.0 - 0.0)) * (c1 - c0)
+        a1 = c0 + ((1.0 - 0.0) / (1.0 - 0.0)) * (c1 - c0)
+        return i, (np.minimum(a0 - r, a1 - r), np.maximum(a0 + r, a1 + r))
+
+    def box(self, lo, hi):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        m = self.material(allow_light=False)
+        sides = [(abi.RT_NODE_XY_RECT, (x0, x1, y0, y1, z1)), (abi.RT_NODE_XY_RECT, (x0, x1, y0, y1, z0)),
+                 (abi.RT_NODE_XZ_RECT, (x0, x1, z0, z1, y1)), (abi.RT_NODE_XZ_RECT, (x0, x1, z0, z1, y0)),
+                 (abi.RT_NODE_YZ_RECT, (y0, y1, z0, z1, x1)), (abi.RT_NODE_YZ_RECT, (y0, y1, z0, z1, x0))]
+        ids = [self.node(k, m, p=p) for k, p in sides]
+        first = len(self.children)
+        self.children.extend(ids)
+        return self.node(abi.RT_NODE_BOX, -1, first, 6, p=(x0, y0, z0, x1, y1, z1)), (np.array(lo, float), np.array(hi, float))
+
+    def rect(self):
+        r = self.rng
+        kind = r.choice([abi.RT_NODE_XY_RECT, abi.RT_NODE_XZ_RECT, abi.RT_NODE_YZ_RECT])
+        a0, b0 = r.uniform(-3, 1, 2)
+        a1, b1 = a0 + r.uniform(0.5, 3), b0 + r.uniform(0.5, 3)
+        k = r.uniform(-3, 4)
+        i = self.node(int(kind), self.material(), p=(a0, a1, b0, b1, k))
+        return i, (np.full(3, -10.0), np.full(3, 10.0))
+
+    def random_leaf(self, boxes=True, moving=True):
+        r = self.rng
+        c = r.uniform(-3, 3, 3) * (1, 0.3, 1) + (0, 0.6, 0)
+        what = r.choice(["sphere", "sphere", "box" if boxes else "sphere", "moving" if moving else "sphere"])
+        if what == "box":
+            lo = c - r.uniform(0.1, 0.5, 3)
+            return self.box(tuple(lo), tuple(lo + r.uniform(0.3, 1.0, 3)))
+        if what == "moving":
+            return self.moving_sphere(c, c + r.uniform(-0.4, 0.4, 3), float(r.uniform(0.15, 0.5)))
+        return self.sphere(c, float(r.uniform(0.15, 0.6)))
+
+    def bvh(self, leaves):
+        """A tree over `leaves` = [(id, box)], split at random points; boxes as bvh_node's constructor computes them."""
+        if len(leaves) == 1:
+            return leaves[0]
+        cut = int(self.rng.integers(1, len(leaves)))
+        (l, lb), (r, rb) = self.bvh(leaves[:cut]), self.bvh(leaves[cut:])
+        lo, hi = np.minimum(lb[0], rb[0]), np.maximum(lb[1], rb[1])
+        return self.node(abi.RT_NODE_BVH, -1, l, r, p=(*lo, *hi)), (lo, hi)
+
+    def instance(self, child):
+        r = self.rng
+        i, box = child
+        if r.random() < 0.6:
+            th = math.radians(float(r.uniform(-60, 60)))
+            i = self.node(abi.RT_NODE_ROTATE_Y, -1, i, 0, p=(math.sin(th), math.cos(th)))
+        off = r.uniform(-1.5, 1.5, 3) * (1, 0.2, 1)
+        return self.node(abi.RT_NODE_TRANSLATE, -1, i, 0, p=tuple(off)), (np.full(3, -12.0), np.full(3, 12.0))
+
+    def medium(self):
+        r = self.rng
+        boundary = self.sphere(r.uniform(-2, 2, 3) * (1, 0.2, 1) + (0, 0.8, 0), float(r.uniform(0.5, 1.2))) if r.random() < 0.5 \
+            else self.box((-1.0, 0.0, -1.0), (0.5, 1.2, 0.6))
+        b = boundary if r.random() < 0.5 else self.instance(boundary)
+        self.mat.append((abi.RT_MAT_ISOTROPIC, self.solid(r.uniform(0.2, 1.0, 3)), (0, 0, 0), 0.0))
+        return self.node(abi.RT_NODE_MEDIUM, len(self.mat) - 1, b[0], 0, p=(-1.0 / float(r.uniform(0.3, 2.0)),)), b[1]
+
+    def finish(self, top, sky):
+        first = len(self.children)
+        self.children.extend(i for i, _ in top)
+        root = self.node(abi.RT_NODE_LIST, -1, first, len(top))
+        nodes = np.zeros(len(self.nodes), abi.NODE_DTYPE)
+        for i, (kind, m, c0, c1, p) in enumerate(self.nodes):
+            nodes[i] = (kind, m, c0, c1, p)
+        mats = np.zeros(len(self.mat), abi.MATERIAL_DTYPE)
+        for i, (kind, t, alb, prm) in enumerate(self.mat):
+            mats[i] = (kind, t, alb, prm)
+        texs = np.zeros(len(self.tex), abi.TEXTURE_DTYPE)
+        for i, (kind, a, b, p) in enumerate(self.tex):
+            texs[i] = (kind, a, b, 0, p)
+        return abi.Scene(root, nodes, np.array(self.children, dtype=np.int32), mats, texs, self.perlin,
+                         images=[np.ascontiguousarray(self.image)], sky_mode=sky, background=(0.6, 0.7, 0.9))
+
+
+def random_world(seed):
+    rng = np.random.default_rng(seed)
+    w = WorldBuilder(rng)
+    top = [w.sphere((0, -1000, 0), 1000.0)]
+    for _ in range(int(rng.integers(4, 9))):
+        what = rng.choice(["leaf", "rect", "instance", "bvh_static", "bvh_any", "bvh_instanced", "list", "medium"])
+        if what == "leaf":
+            top.append(w.random_leaf())
+        elif what == "rect":
+            top.append(w.rect())
+        elif what == "instance":
+            top.append(w.instance(w.random_leaf(moving=False)))
+        elif what == "bvh_static":  # a leaf set when RT_SUBTREE_SET_MIN allows
+            top.append(w.bvh([w.random_leaf(moving=False) for _ in range(int(rng.integers(2, 12)))]))
+        elif what == "bvh_any":     # moving spheres keep the tree
+            top.append(w.bvh([w.random_leaf() for _ in range(int(rng.integers(2, 8)))]))
+        elif what == "bvh_instanced":
+            top.append(w.instance(w.bvh([w.random_leaf(moving=False) for _ in range(int(rng.integers(2, 10)))])))
+        elif what == "list":
+            kids = [w.random_leaf() for _ in range(int(rng.integers(1, 4)))]
+            first = len(w.children)
+            w.children.extend(i for i, _ in kids)
+            top.append((w.node(abi.RT_NODE_LIST, -1, first, len(kids)), None))
+        else:
+            top.append(w.medium())
+    return w.finish(top, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_world_matches_oracle(seed, monkeypatch):
+    scene = random_world(1000 + seed)
+    mk = lambda f: f((7, 3.5, 8), (0, 0.7, 0), (0, 1, 0), 32.0, 4.0 / 3.0, 0.05, 10.0, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(56, 42, 4, 50, seed=seed)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    want = fixed.astype(np.float64) / FRAC
+    want_ids = ob.first_hit(scene, ocam, 72, 54)
+    for set_min in (2, 1000):  # BVH subtrees of static leaves as leaf sets / walked as trees
+        monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+        c = lib.Context(0)
+        try:
+            c.upload(scene)
+            got, st = c.render(cam, p)
+            ids = c.first_hit(cam, 72, 54)
+        finally:
+            c.close()
+        assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, set_min)
+        assert np.array_equal(got, want), (seed, set_min, np.abs(got - want).max())
+        assert np.array_equal(ids, want_ids), (seed, set_min)
