@@ -197,3 +197,75 @@ def test_random_world_matches_oracle(seed, monkeypatch):
         assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, set_min)
         assert np.array_equal(got, want), (seed, set_min, np.abs(got - want).max())
         assert np.array_equal(ids, want_ids), (seed, set_min)
+
+
+def random_sphere_world(seed):
+    """Spheres and moving spheres only, in random nestings of lists and BVH nodes: runs on the sphere-list kernels."""
+    rng = np.random.default_rng(seed)
+    w = WorldBuilder(rng)
+    w.material = lambda allow_light=True, _m=w.material: _pick_sphere_world_material(w, _m)
+    n = int(rng.choice([1, 2, 31, 33, 64, 130, 520]))
+    leaves = []
+    for _ in range(n):
+        c = rng.uniform(-6, 6, 3) * (1, 0.1, 1) + (0, 0.4, 0)
+        if rng.random() < 0.4:
+            t0 = float(rng.choice([0.0, -1.0]))
+            leaf = w.moving_sphere(c, c + rng.uniform(-0.5, 0.5, 3), float(rng.uniform(0.1, 0.45)))
+            i = leaf[0]
+            kind, m, c0, c1, p = w.nodes[i]
+            p[6], p[7] = t0, t0 + float(rng.choice([1.0, 3.0]))
+            c0v, c1v, r = p[:3], p[3:6], p[8]
+            a0 = c0v + ((p[6] - p[6]) / (p[7] - p[6])) * (c1v - c0v)
+            a1 = c0v + ((p[7] - p[6]) / (p[7] - p[6])) * (c1v - c0v)
+            leaf = (i, (np.minimum(a0 - r, a1 - r), np.maximum(a0 + r, a1 + r)))
+        else:
+            leaf = w.sphere(c, float(rng.uniform(0.1, 0.5)))
+        leaves.append(leaf)
+    top = [w.sphere((0, -1000, 0), 1000.0)]
+    while leaves:
+        take = int(rng.integers(1, len(leaves) + 1))
+        group, leaves = leaves[:take], leaves[take:]
+        how = rng.choice(["bvh", "list", "each"])
+        if how == "bvh":
+            top.append(w.bvh(group))
+        elif how == "list":
+            first = len(w.children)
+            w.children.extend(i for i, _ in group)
+            top.append((w.node(abi.RT_NODE_LIST, -1, first, len(group)), None))
+        else:
+            top.extend(group)
+    return w.finish(top, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])))
+
+
+def _pick_sphere_world_material(w, general):
+    while True:
+        m = general(False)
+        kind, tex = w.mat[m][0], w.mat[m][1]
+        if kind != abi.RT_MAT_LAMBERTIAN or w.tex[tex][0] in (abi.RT_TEX_SOLID, abi.RT_TEX_CHECKER):
+            return m
+        w.mat.pop()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_sphere_world_matches_oracle(seed):
+    scene = random_sphere_world(2000 + seed)
+    rng = np.random.default_rng(seed)
+    t0, t1 = [(0.0, 1.0), (0.25, 0.5), (0.0, 0.0), (-0.5, 1.5)][seed % 4]  # the last one leaves some sweeps: graph walk
+    aperture = float(rng.choice([0.0, 0.1]))
+    mk = lambda f: f((9, 3.0, 9), (0, 0.3, 0), (0, 1, 0), 40.0, 4.0 / 3.0, aperture, 12.0, t0, t1)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(56, 42, 4, 50, seed=seed)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        got, st = c.render(cam, p)
+        ids = c.first_hit(cam, 72, 54)
+        c.set_exact_only(True)
+        exact, _ = c.render(cam, p)
+    finally:
+        c.close()
+    assert st["rays"] == ost["rays"], seed
+    assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, t0, t1)
+    assert np.array_equal(got, exact)
+    assert np.array_equal(ids, ob.first_hit(scene, ocam, 72, 54)), seed
