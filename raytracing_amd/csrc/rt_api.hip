@@ -656,6 +656,23 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             set_nodes.insert(set_nodes.end(), boxes.begin(), boxes.end());
         }
     }
+    std::vector<TopEntry> tops;
+    {
+        const rt_node& root = sc->nodes[sc->root];
+        for (int i = 0; i < root.child1; ++i) {
+            TopEntry te{};
+            te.first = sc->children[root.child0 + i];
+            int idx = te.first;
+            while (te.chain_len < XF_DEPTH_CAP && (sc->nodes[idx].kind == RT_NODE_TRANSLATE || sc->nodes[idx].kind == RT_NODE_ROTATE_Y ||
+                                                   sc->nodes[idx].kind == RT_NODE_FLIP_FACE)) {
+                te.chain[te.chain_len++] = idx;
+                idx = sc->nodes[idx].child0;
+            }
+            te.node = idx;
+            te.end = nodes[(size_t)idx];  // after the conversions above: boxes and leaf sets carry their device kinds
+            tops.push_back(te);
+        }
+    }
     std::vector<int32_t> children(sc->children, sc->children + sc->n_children);
     const std::vector<MaterialDev> mats = device_materials(sc);
     std::vector<TextureDev> texs((size_t)sc->n_textures);
@@ -694,6 +711,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     if ((rc = to_device(ctx, texs, &G.textures)) != RT_OK) return rc;
     if ((rc = to_device(ctx, perlins, &G.perlins)) != RT_OK) return rc;
     if ((rc = to_device(ctx, images, &G.images)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, tops, &G.tops)) != RT_OK) return rc;
+    G.n_tops = (int32_t)tops.size();
     if ((rc = to_device(ctx, sets, &G.sets)) != RT_OK) return rc;
     if ((rc = to_device(ctx, set_nodes, &G.set_nodes)) != RT_OK) return rc;
     std::vector<int32_t> lights;

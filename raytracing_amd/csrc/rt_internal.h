@@ -132,6 +132,16 @@ struct SceneNode {
     double p[6];   // sphere: c, r | moving sphere: c0, c1 | rect: a0 a1 b0 b1 k | BVH: box | box: corners | translate: offset
                    // | rotate_y: sin, cos | medium: neg_inv_density
 };
+// One entry per object of the world list, in list order: what the wave-level walk needs to know about it in one
+// scalar load -- the instance chain above it (outermost first) and a copy of the node below the chain.
+struct TopEntry {
+    int32_t node;       // the node below the chain (the object itself when chain_len == 0)
+    int32_t chain_len;  // translate / rotate_y / flip_face nodes above it, at most XF_DEPTH_CAP
+    int32_t chain[4];
+    int32_t first;      // the object's own node id (= chain[0] when there is a chain)
+    int32_t pad;
+    SceneNode end;      // copy of nodes[node]
+};
 struct TextureDev {
     int32_t kind, a, b, pad;  // RT_TEX_*; checker: even, odd; noise: perlin index; image: image index or -1
     double p[4];              // solid: colour; noise: scale
@@ -148,6 +158,8 @@ struct SceneDev {
     const int32_t* children;
     const int32_t* parent_xf;  // per node: enclosing translate/rotate_y node, or -1
     const int32_t* top_of;     // per node: index within the root list of the top-level object containing it
+    const TopEntry* tops;      // per object of the root list
+    int32_t n_tops;
     const double* extra;
     const MaterialDev* materials;
     const TextureDev* textures;

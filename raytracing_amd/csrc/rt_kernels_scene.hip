@@ -243,6 +243,14 @@ __device__ __forceinline__ bool boundary_hit(const SceneDev& S, int node, Ray r,
         n = S.nodes[n.a];
     }
     const double a = len2(r.d);
+    if constexpr ((F & F_RECT) != 0) {
+        if (n.kind == DEV_NODE_BOX6) {  // the six sides from the corners: the list's tests, order and closest-so-far rule
+            double best = t_max;
+            const bool any = hit_box6(n.p, r, t_min, best) >= 0;
+            t_out = best;
+            return any;
+        }
+    }
     if (n.kind == RT_NODE_LIST || n.kind == RT_NODE_BOX || n.kind == DEV_NODE_BOX6) {
         bool any = false;
         double best = t_max;
@@ -306,10 +314,19 @@ __device__ __forceinline__ void medium_hit(const SceneDev& S, const SceneNode& n
 #ifdef RT_SCENE_PROBE
 // debug build: per-lane counters of the traversal loop, summed and printed by the render kernel
 static __device__ unsigned long long g_probe_total[16];  // [kind] entries, [12] trips, [13] lane-trips, [14] traces
+// wave cycles per section of the render loop
+enum { PS_REFILL = 0, PS_TOP_PRIM, PS_TOP_BOX, PS_TOP_MEDIUM, PS_SET_SPHERES, PS_SET_BOXES, PS_STACK_WALK, PS_SHADE, PS_COUNT };
+static __device__ unsigned long long g_probe_cycles[PS_COUNT];
+#define PROBE_MARK(k) do { const unsigned long long now_ = clock64(); if (lane == 0) atomicAdd(&g_probe_cycles[k], now_ - probe_t); probe_t = now_; } while (0)
+#else
+#define PROBE_MARK(k) do { } while (0)
 #endif
 template <int F>
 __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, uint32_t* stack, int lane,
                                      const RngCtx& g) {
+#ifdef RT_SCENE_PROBE
+    unsigned long long probe_t = clock64();
+#endif
     Hit h{__builtin_inf(), -1, -1};
     Ray cur = w;
     int cur_xf = -1;
@@ -322,23 +339,15 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
     // together and leave it together.  Each lane still meets the objects in list order with its own
     // closest-so-far value, but the lanes of a trip are now inside the same object: a sphere or a medium of the
     // world is tested by all lanes at once, and inside a BVH only box code and its leaves' code are live.
-    const int top_first = __builtin_amdgcn_readfirstlane(S.nodes[S.root].a);
-    const int top_count = __builtin_amdgcn_readfirstlane(S.nodes[S.root].b);
-    for (int top = 0; top < top_count; ++top) {
-    const int top_node = __builtin_amdgcn_readfirstlane(S.children[top_first + top]);
+    typedef __attribute__((address_space(4))) TopEntry ConstTopEntry;  // immutable for the launch: scalar loads
+    const ConstTopEntry* tops = (const ConstTopEntry*)S.tops;
+    for (int top = 0; top < S.n_tops; ++top) {
+    const int top_node = tops[top].first;
     {   // An object of the world that is a primitive, a box, a medium or a leaf set, by itself or under a chain of
         // instances, is the same node for every lane: its data come through scalar loads and nothing goes through
         // the stack.
-        int node = top_node, chain = 0;
-        int kind = __builtin_amdgcn_readfirstlane(S.nodes[node].kind);
-        if constexpr ((F & F_XF) != 0) {
-            while (chain < XF_DEPTH_CAP && (kind == RT_NODE_TRANSLATE || kind == RT_NODE_ROTATE_Y ||
-                                            ((F & F_FLIP) != 0 && kind == RT_NODE_FLIP_FACE))) {
-                node = __builtin_amdgcn_readfirstlane(S.nodes[node].a);
-                kind = __builtin_amdgcn_readfirstlane(S.nodes[node].kind);
-                ++chain;
-            }
-        }
+        const int node = tops[top].node, chain = tops[top].chain_len;
+        const int kind = tops[top].end.kind;
         const bool plain = kind >= RT_NODE_SPHERE && kind <= RT_NODE_YZ_RECT;
         const bool box6 = (F & F_RECT) != 0 && kind == DEV_NODE_BOX6;
         const bool medium = (F & F_MEDIUM) != 0 && kind == RT_NODE_MEDIUM;
@@ -347,15 +356,20 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             Ray loc = w;
             int loc_xf = -1;
             if constexpr ((F & F_XF) != 0) {
-                int x = top_node;
                 for (int i = 0; i < chain; ++i) {  // the rays handed down by translate::hit / rotate_y::hit, outermost first
+                    const int x = tops[top].chain[i];
                     const SceneNode xn = S.nodes[x];
                     if (!((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE)) loc = xf_apply(xn, loc);
                     loc_xf = x;
-                    x = xn.a;
                 }
             }
-            const SceneNode n = S.nodes[node];
+            SceneNode n;
+            n.kind = kind;
+            n.a = tops[top].end.a;
+            n.b = tops[top].end.b;
+            n.c = tops[top].end.c;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) n.p[k] = tops[top].end.p[k];
             if (plain) {
                 double t;
                 if (on && prim_hit<F>(S, n, loc, len2(loc.d), tm, T_MIN, h.t, t)) {
@@ -363,6 +377,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     h.node = node;
                     h.xf = loc_xf;
                 }
+                PROBE_MARK(PS_TOP_PRIM);
             } else if (box6) {
                 if constexpr ((F & F_RECT) != 0) {
                     const int side = on ? hit_box6(n.p, loc, T_MIN, h.t) : -1;
@@ -371,10 +386,12 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         h.xf = loc_xf;
                     }
                 }
+                PROBE_MARK(PS_TOP_BOX);
             } else if (medium) {
                 if constexpr ((F & F_MEDIUM) != 0) {
                     if (on) medium_hit<F>(S, n, node, loc, loc_xf, tm, g, h);
                 }
+                PROBE_MARK(PS_TOP_MEDIUM);
             } else {
                 if constexpr ((F & F_SET) != 0) {
                     // bvh_node::hit's own box test (B2/bvh.h:98-99), then the subtree's leaves as a flat set: the
@@ -405,6 +422,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 }
                             });
                             best_t = sh.t;
+                            PROBE_MARK(PS_SET_SPHERES);
                         }
                         if constexpr ((F & F_RECT) != 0) {
                             if (set.boxes.n > 0) {
@@ -418,6 +436,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                     }
                                 });
                                 best_t = bh.t;
+                                PROBE_MARK(PS_SET_BOXES);
                             }
                         }
                         if (mine && winner >= 0) {
@@ -501,6 +520,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             }
         }
     }
+    PROBE_MARK(PS_STACK_WALK);
     }
     return h;
 }
@@ -796,6 +816,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     const WorkQueues Q{A.item_counter, A.n_items, A.accum, nullptr};  // no accumulation cache: these kernels are short of registers
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0;
 
+#ifdef RT_SCENE_PROBE
+    unsigned long long probe_t = clock64();
+#endif
     for (;;) {
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
         if (!active && w.has_item) {
@@ -808,7 +831,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         }
         const bool on = active;
         const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
+        PROBE_MARK(PS_REFILL);
         const Hit h = trace<F>(S, r, tm, on, stack, lane, g);
+#ifdef RT_SCENE_PROBE
+        probe_t = clock64();  // trace() accounts for its own sections
+#endif
 
         if (on) {
             ++n_rays;
@@ -886,6 +913,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 ++w.s_cur;
             }
         }
+        PROBE_MARK(PS_SHADE);
     }
 
     uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad;
@@ -991,6 +1019,15 @@ void scene_probe_dump() {
         if (h[k]) std::fprintf(stderr, "  entries %-9s %12llu  (%.2f per lane-trip)\n", names[k], h[k], (double)h[k] / (double)h[13]);
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_total), z, sizeof(z));
+    unsigned long long c[PS_COUNT];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_probe_cycles), sizeof(c)) != hipSuccess) return;
+    static const char* sections[] = {"refill + camera", "top-level primitives", "top-level boxes", "top-level media", "leaf sets: spheres",
+                                     "leaf sets: boxes", "stack walk", "shade"};
+    unsigned long long total = 0;
+    for (int k = 0; k < PS_COUNT; ++k) total += c[k];
+    for (int k = 0; k < PS_COUNT; ++k)
+        std::fprintf(stderr, "  wave cycles %-22s %14llu  %5.1f %%\n", sections[k], c[k], 100.0 * (double)c[k] / (double)(total ? total : 1));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cycles), z, sizeof(c));
 }
 #endif
 

@@ -15,7 +15,7 @@ for name in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["bouncing", "fina
     cam = lib.camera(k["lookfrom"], k["lookat"], (0, 1, 0), k["vfov"], k["aspect"], k["aperture"], 10.0, 0.0, 1.0)
     ctx.upload(sc)
     ctx.take_stats()
-    _, st = ctx.render(cam, abi.render_params(300, 300, 4, 50, seed=1))
+    _, st = ctx.render(cam, abi.render_params(400, 400, 8, 50, seed=1))
     print(f"== {name}: rays {st['rays']} samples {st['samples']}", flush=True)
     sys.stderr.flush()
 ctx.close()
