@@ -665,6 +665,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             int idx = te.first;
             while (te.chain_len < XF_DEPTH_CAP && (sc->nodes[idx].kind == RT_NODE_TRANSLATE || sc->nodes[idx].kind == RT_NODE_ROTATE_Y ||
                                                    sc->nodes[idx].kind == RT_NODE_FLIP_FACE)) {
+                te.chain_kind[te.chain_len] = sc->nodes[idx].kind;
+                for (int k = 0; k < 3; ++k) te.chain_p[te.chain_len][k] = nodes[(size_t)idx].p[k];
                 te.chain[te.chain_len++] = idx;
                 idx = sc->nodes[idx].child0;
             }

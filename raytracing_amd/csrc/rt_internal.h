@@ -141,6 +141,8 @@ struct TopEntry {
     int32_t first;      // the object's own node id (= chain[0] when there is a chain)
     int32_t pad;
     SceneNode end;      // copy of nodes[node]
+    int32_t chain_kind[4];   // RT_NODE_TRANSLATE / ROTATE_Y / FLIP_FACE per chain level
+    double chain_p[4][3];    // translate: offset; rotate_y: sin, cos
 };
 struct TextureDev {
     int32_t kind, a, b, pad;  // RT_TEX_*; checker: even, odd; noise: perlin index; image: image index or -1

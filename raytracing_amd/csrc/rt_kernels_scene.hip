@@ -357,10 +357,13 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             int loc_xf = -1;
             if constexpr ((F & F_XF) != 0) {
                 for (int i = 0; i < chain; ++i) {  // the rays handed down by translate::hit / rotate_y::hit, outermost first
-                    const int x = tops[top].chain[i];
-                    const SceneNode xn = S.nodes[x];
+                    SceneNode xn;
+                    xn.kind = tops[top].chain_kind[i];
+                    xn.p[0] = tops[top].chain_p[i][0];
+                    xn.p[1] = tops[top].chain_p[i][1];
+                    xn.p[2] = tops[top].chain_p[i][2];
                     if (!((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE)) loc = xf_apply(xn, loc);
-                    loc_xf = x;
+                    loc_xf = tops[top].chain[i];
                 }
             }
             SceneNode n;
