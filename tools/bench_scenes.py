@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of the book-2 worlds (BASELINE configs 3 and 4, and the Cornell box) at full frame size and a
+"""Kernel time of the book-2 worlds (bouncing spheres, final scene, Cornell boxes, Perlin spheres) at full frame size and a
 few samples per pixel.  RT_LIB_PATH selects the library under test."""
 import json
 import os
