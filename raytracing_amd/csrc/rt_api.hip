@@ -308,6 +308,9 @@ struct SphereSetWalk {
             }
             if ((int)prims.size() >= max_spheres) return false;
             if (graph_leaves && n.kind != RT_NODE_SPHERE) return false;
+            // a negative radius (the hollow-glass trick of book 1) turns sphere::bounding_box inside out: node boxes
+            // built from it do not enclose the sphere, and the tree walk culls what a list would hit
+            if (!((n.kind == RT_NODE_SPHERE ? n.p[3] : n.p[8]) > 0.0)) return false;
             if (n.kind == RT_NODE_SPHERE) {
                 box = around(n.p, n.p[3]);
             } else {  // p = centre0, centre1, time0, time1, radius

@@ -406,3 +406,16 @@ def test_box_subtrees_inside_a_graph_match_oracle(monkeypatch, scale, lookfrom, 
         assert st["rays"] == ost["rays"], set_min
         assert np.array_equal(got, want), (set_min, np.abs(got - want).max())
         assert np.array_equal(ids, want_ids), set_min
+
+
+def test_negative_radius_under_a_bvh_keeps_the_tree(ctx):
+    """sphere::bounding_box of a negative radius is inside out, so the reference's tree culls hits a list would find:
+    such worlds are walked as trees, and match the oracle's tree walk."""
+    scene = nested_world()
+    scene.nodes[8]["p"][3] = -0.5  # the metal sphere under bvh 7 (the node boxes still enclose it: |r| is unchanged)
+    ctx.upload(scene)
+    check_against_oracle(ctx, scene, 0.0, 1.0, abi.RT_KERNELS_SCENE_GRAPH)
+    flat = nested_world()
+    flat.nodes[5]["p"][3] = -0.9  # the glass sphere directly in a list: no box involved, but still not a sphere world
+    ctx.upload(flat)
+    check_against_oracle(ctx, flat, 0.0, 1.0, abi.RT_KERNELS_SCENE_GRAPH)
