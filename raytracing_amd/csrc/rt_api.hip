@@ -1019,6 +1019,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);
         A.importance = importance ? 1 : 0;
+        A.exact_only = (ctx->exact_only || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
         A.accum = d_accum_fixed;
         A.item_counter = ctx->d_counter;
         A.stats = ctx->d_stats;
@@ -1159,6 +1160,7 @@ int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int heig
         fill_camera(A.cam, cam);
         A.width = width;
         A.height = height;
+        A.exact_only = ctx->exact_only ? 1 : 0;
         A.ids = ctx->d_ids;
         HIP_TRY(ctx, launch_first_hit_scene(A, ctx->stream));
     }

@@ -67,10 +67,17 @@ __device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const
 
 // Closest hit in [t_min, t_max] of one ray per lane against the boxes of the set; exact(j, h) is the reference's test
 // of box j (lowers h.t and sets h.id = j on a hit).  Must be called by all 64 lanes; `list` as for the spheres.
+// exact_only must be the same for the whole wave.
 template <class ExactFn>
-__device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d, double t_max, bool on, uint16_t* list,
-                                                  int lane, ExactFn exact) {
+__device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d, double t_max, bool on, bool exact_only,
+                                                  uint16_t* list, int lane, ExactFn exact) {
     SetHit h{t_max, -1};
+    if (exact_only) {  // validation: no float screen, every box in double
+        if (on) {
+            for (int j = 0; j < B.n; ++j) exact(j, h);
+        }
+        return h;
+    }
     const BoxScreenRay sr = box_screen_prepare(o, d, B.cover);
     uint32_t cnt = (on && !sr.covered) ? (uint32_t)CAND_CAP + 1u : 0u;
     const ConstBoxPair* bp = (const ConstBoxPair*)B.screen;

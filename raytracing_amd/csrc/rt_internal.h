@@ -189,6 +189,7 @@ struct SceneRenderArgs {
     uint32_t n_items;
     uint32_t key0, key1;
     int32_t importance;  // 1: ray_color of book 3 (RT_RENDER_IMPORTANCE)
+    int32_t exact_only;  // 1: leaf sets skip their float screens and test every leaf in double (validation)
     int64_t* accum;
     uint32_t* item_counter;
     uint64_t* stats;
@@ -197,6 +198,7 @@ struct SceneFirstHitArgs {
     SceneDev scene;
     CameraDev cam;
     int32_t width, height;
+    int32_t exact_only;
     int32_t* ids;
 };
 hipError_t launch_render_scene(const SceneRenderArgs& args, int blocks, hipStream_t stream);

@@ -322,8 +322,8 @@ static __device__ unsigned long long g_probe_cycles[PS_COUNT];
 #define PROBE_MARK(k) do { } while (0)
 #endif
 template <int F>
-__device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, uint32_t* stack, int lane,
-                                     const RngCtx& g) {
+__device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, bool exact_only, uint32_t* stack,
+                                     int lane, const RngCtx& g) {
 #ifdef RT_SCENE_PROBE
     unsigned long long probe_t = clock64();
 #endif
@@ -413,7 +413,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         if (set.spheres.n > 0) {
                             uint32_t overflowed = 0;
                             ProbeClock clk;
-                            const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, false, list, rows, lane, overflowed, clk,
+                            const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, overflowed, clk,
                                                                [&](int j, SetHit& best) {
                                 const int id = S.set_nodes[first_slot + j];
                                 const SceneNode sn = S.nodes[id];
@@ -430,7 +430,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         if constexpr ((F & F_RECT) != 0) {
                             if (set.boxes.n > 0) {
                                 const int first_box = first_slot + set.spheres.n;
-                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, list, lane, [&](int j, SetHit& best) {
+                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, lane, [&](int j, SetHit& best) {
                                     const SceneNode bn = S.nodes[S.set_nodes[first_box + j]];
                                     const int side = hit_box6(bn.p, loc, T_MIN, best.t);
                                     if (side >= 0) {
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         const bool on = active;
         const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
         PROBE_MARK(PS_REFILL);
-        const Hit h = trace<F>(S, r, tm, on, stack, lane, g);
+        const Hit h = trace<F>(S, r, tm, on, A.exact_only != 0, stack, lane, g);
 #ifdef RT_SCENE_PROBE
         probe_t = clock64();  // trace() accounts for its own sections
 #endif
@@ -955,7 +955,7 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
     const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
     const Ray r{origin + offset, llc + s * hor + t * ver - origin - offset};
     const RngCtx g{pc, 0u, 1u, 0u, 0u};
-    const Hit h = trace<F_EVERY>(A.scene, r, C.time0, on, stack, lane, g);
+    const Hit h = trace<F_EVERY>(A.scene, r, C.time0, on, A.exact_only != 0, stack, lane, g);
     if (on) A.ids[pixel] = h.node < 0 ? -1 : A.scene.top_of[h.node];
 }
 

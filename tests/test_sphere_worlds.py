@@ -329,6 +329,16 @@ def test_final_scene_sphere_cube_as_a_set(monkeypatch, kat_b2):
     assert sa["rays"] == sb["rays"] and np.array_equal(a, b) and np.array_equal(ids_a, ids_b)
     rows = ob.render_rows(scene, camera_b2(k), p, 60, 62, has_time=True) / FRAC
     assert np.array_equal(a[60:62], rows)
+    # validation switch: the same sets with their float screens bypassed (every leaf tested in double)
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        c.set_exact_only(True)
+        e, se = c.render(cam, p)
+        ids_e = c.first_hit(cam, 200, 200)
+    finally:
+        c.close()
+    assert se["rays"] == sa["rays"] and np.array_equal(e, a) and np.array_equal(ids_e, ids_a)
 
 
 def box_field_world(scale=1.0):
