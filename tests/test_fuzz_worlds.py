@@ -192,8 +192,11 @@ def test_random_world_matches_oracle(seed, monkeypatch):
             c.upload(scene)
             got, st = c.render(cam, p)
             ids = c.first_hit(cam, 72, 54)
+            c.set_exact_only(True)  # leaf sets without their float screens
+            exact, _ = c.render(cam, p)
         finally:
             c.close()
+        assert np.array_equal(got, exact), (seed, set_min)
         assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, set_min)
         assert np.array_equal(got, want), (seed, set_min, np.abs(got - want).max())
         assert np.array_equal(ids, want_ids), (seed, set_min)
