@@ -61,7 +61,7 @@ def cpu_baseline(scene_path):
     """The reference renderer itself (oracle/_ref/ref_b1, compiled from the unmodified sources in the
     development container), one thread, on a bounded sample of the same workload; falls back to the
     oracle's rand()-faithful port when that binary is absent."""
-    W, H, spp = 240, 160, 32
+    W, H, spp = 240, 160, 96  # about 11 s of one core
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_b1")
     sample = f"config-2 scene and camera, {W}x{H}, {spp} spp, depth 50 ({W * H * spp / 1e6:.2f} Msamples)"
     if os.path.exists(ref):
@@ -89,7 +89,7 @@ def cpu_baseline_all_cores(processes):
     """The reference author's own recipe for more cores ("Ray Tracing In a Weekend/README.md":2538-2542): P copies of
     the reference renderer, each with its own seed and spp/P samples, images averaged afterwards.  Context only: P
     processes of the unmodified reference on the same bounded sample as cpu_baseline, started together."""
-    W, H, spp = 240, 160, 32
+    W, H, spp = 240, 160, 96
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_b1")
     if not os.path.exists(ref) or processes < 2:
         return None
