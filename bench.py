@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams (each with its own accumulation "
                          "buffer), so that the long-path tail of one frame and its all-reduce overlap the next "
-                         "frame.  Default: 1 on one GPU (kernel timings stay per launch), 2 with several ranks")
+                         "frame.  Default: 1 on one GPU (kernel timings stay per launch), 3 with several ranks (with 2, "
+                         "frame k+2 would queue behind the all-reduce of frame k on the same stream, and that collective "
+                         "only finds free CUs once frame k+1 nears its end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -158,7 +160,7 @@ def main():
     # One slot per frame in flight: its own HIP stream, library context (the scene is tiny: one copy per slot)
     # and accumulation buffer.  Frame k runs entirely on slot k % n: zero -> render kernel -> all-reduce
     # (frame.FramePipeline orders the all-reduce of frame k-1 after the launch of frame k).
-    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
     slots = []
     for _ in range(n_slots):
         s = torch.cuda.Stream(device=dev)
