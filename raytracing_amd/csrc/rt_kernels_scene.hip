@@ -15,6 +15,14 @@
 // the role of the t_max the reference threads through its calls.  Every test is done in double with the
 // reference's operation order, so winner, t, hit point and normal are the reference's, bit for bit.
 // A hit only records (t, node, enclosing instance); the full hit record is rebuilt once, for the winner.
+//
+// Three levels of the walk, from the outside in:
+//   1. the world list is walked by the wave as a whole (all lanes enter and leave its k-th object together);
+//   2. an object that is a primitive, a box, a medium or a leaf set -- by itself or under an instance chain -- is
+//      evaluated right there from a per-object table read with scalar loads; a leaf set (a BVH subtree of spheres and
+//      boxes whose node boxes enclose their leaves) is screened in float by the whole wave and only its few
+//      candidates are tested in double (rt_sphere_screen.h, rt_box_screen.h);
+//   3. everything else (lists, BVH trees with other leaves) goes through the per-lane stack.
 #include <cstdio>
 
 #include "rt_device_common.h"
