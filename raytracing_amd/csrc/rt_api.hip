@@ -45,6 +45,7 @@ struct rt_context {
     // screening image bounds every moving sphere over [sweep_lo, sweep_hi]; a camera whose shutter interval leaves
     // that range is rendered from the graph.
     bool spheres_timed = false;
+    bool screen_unsafe = false;  // the sphere list holds values the float screen cannot take: double tests only
     double sweep_lo = 0.0, sweep_hi = 0.0;
     int sphere_set_max = 2048;  // above this many spheres the BVH walk of the graph kernels wins (RT_SPHERE_SET_MAX)
     // inside a graph, a BVH subtree of at least / at most this many static spheres and boxes is evaluated as a leaf set
@@ -393,6 +394,19 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
 // Device image of the spheres `prims` (node ids, in list order) for the screening + exact passes.  With `timed`
 // every sphere also gets a motion record, and the screening image holds, for a moving sphere, a sphere that bounds
 // its sweep over its own [time0, time1]; sweep_lo / sweep_hi return the interval common to all moving spheres.
+// The float screen squares coordinates and radii: beyond about 1e15 (or with non-finite values) its products leave the
+// float range and the error bound no longer holds.  Such spheres are tested in double only.
+static bool spheres_fit_float_screen(const rt_scene_desc* sc, const std::vector<int>& prims) {
+    for (int id : prims) {
+        const rt_node& nd = sc->nodes[id];
+        const int used = nd.kind == RT_NODE_MOVING_SPHERE ? 6 : 4;
+        for (int k = 0; k < used; ++k)
+            if (!(std::fabs(nd.p[k]) <= 1e15)) return false;
+        if (nd.kind == RT_NODE_MOVING_SPHERE && !(std::fabs(nd.p[8]) <= 1e15)) return false;
+    }
+    return true;
+}
+
 static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, bool timed,
                             SphereSetDev& S, double& sweep_lo, double& sweep_hi) {
     const int n = (int)prims.size();
@@ -517,6 +531,7 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
     S.sky_mode = sc->sky_mode;
     for (int c = 0; c < 3; ++c) S.background[c] = sc->background[c];
     ctx->spheres_timed = timed;
+    ctx->screen_unsafe = !spheres_fit_float_screen(sc, prims);
     ctx->path = PATH_SPHERE_LIST;
     return RT_OK;
 }
@@ -646,6 +661,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
                     for (int k = 0; k < 6; ++k) coord_max = std::fmax(coord_max, std::fabs(leaf.p[k]));
             }
             if (!(coord_max <= 8e6)) continue;  // the slab screen's bound assumes it (also rejects NaN)
+            if (!spheres_fit_float_screen(sc, spheres)) continue;
             LeafSetDev sd{};
             double lo, hi;
             int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, sd.spheres, lo, hi);
@@ -991,7 +1007,7 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);
-        A.exact_only = (ctx->exact_only || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
+        A.exact_only = (ctx->exact_only || ctx->screen_unsafe || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
         A.accum = d_accum_fixed;
         A.item_counter = ctx->d_counter;
         A.stats = ctx->d_stats;
@@ -1151,7 +1167,7 @@ int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int heig
         fill_camera(A.cam, cam);
         A.width = width;
         A.height = height;
-        A.exact_only = ctx->exact_only ? 1 : 0;
+        A.exact_only = (ctx->exact_only || ctx->screen_unsafe) ? 1 : 0;
         A.ids = ctx->d_ids;
         HIP_TRY(ctx, launch_first_hit_spheres(A, ctx->spheres_timed, ctx->stream));
     } else {

@@ -306,3 +306,20 @@ def test_config2_full_size_properties(ctx, scene_c2):
     p = abi.render_params(W, H, 8, 50, seed=1)
     for row in (0, 399, 799):
         assert np.array_equal(a[row], ob.render_rows(scene_c2, cam, p, row, row + 1)[0] / FRAC)
+
+
+def test_spheres_beyond_the_float_screens_range_are_tested_in_double(ctx):
+    """A ground sphere of radius 1e19: its squares leave the float range, so the world is rendered without the float
+    screen -- and still equals the oracle bit for bit."""
+    scene = abi.load_scene(gold("scene_c1.rtsc"))
+    spheres = np.flatnonzero(scene.nodes["kind"] == abi.RT_NODE_SPHERE)
+    ground = spheres[int(np.argmax(scene.nodes["p"][spheres, 3]))]
+    scene.nodes["p"][ground][:4] = (0.0, -1.0e19 - 0.5, -1.0, 1.0e19)
+    cam = lib.camera(*CAM_C1)
+    ctx.upload(scene)
+    p = abi.render_params(80, 45, 6, 50, seed=3)
+    got, st = ctx.render(cam, p)
+    _, fixed, ost = ob.render(scene, ob.camera(*CAM_C1), p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=8)
+    assert st["rays"] == ost["rays"]
+    assert np.array_equal(got, fixed.astype(np.float64) / 2.0 ** abi.RT_ACCUM_FRAC_BITS)
+    assert np.array_equal(ctx.first_hit(cam, 120, 68), ob.first_hit(scene, ob.camera(*CAM_C1), 120, 68))
