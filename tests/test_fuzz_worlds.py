@@ -272,3 +272,63 @@ def test_random_sphere_world_matches_oracle(seed):
     assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, t0, t1)
     assert np.array_equal(got, exact)
     assert np.array_equal(ids, ob.first_hit(scene, ocam, 72, 54)), seed
+
+
+def random_is_world(seed):
+    """A world for RT_RENDER_IMPORTANCE (ray_color of book 3): no media, a lamp behind a flip_face wrapper, and a
+    light list (outside the world graph) of an xz_rect like the lamp and, sometimes, a glass sphere of the world."""
+    rng = np.random.default_rng(seed)
+    w = WorldBuilder(rng)
+    top = [w.sphere((0, -1000, 0), 1000.0)]
+    for _ in range(int(rng.integers(3, 8))):
+        what = rng.choice(["leaf", "rect", "instance", "bvh_static", "bvh_instanced"])
+        if what == "leaf":
+            top.append(w.random_leaf(moving=False))
+        elif what == "rect":
+            top.append(w.rect())
+        elif what == "instance":
+            top.append(w.instance(w.random_leaf(moving=False)))
+        elif what == "bvh_static":
+            top.append(w.bvh([w.random_leaf(moving=False) for _ in range(int(rng.integers(2, 10)))]))
+        else:
+            top.append(w.instance(w.bvh([w.random_leaf(moving=False) for _ in range(int(rng.integers(2, 8)))])))
+    # the lamp: an xz_rect emitter seen through flip_face (it emits from its front face only: downwards after the flip)
+    x0, z0 = rng.uniform(-2, 0, 2)
+    lamp_p = (x0, x0 + float(rng.uniform(1, 2.5)), z0, z0 + float(rng.uniform(1, 2.5)), float(rng.uniform(3.0, 4.5)))
+    w.mat.append((abi.RT_MAT_DIFFUSE_LIGHT, w.solid((8.0, 8.0, 8.0)), (0, 0, 0), 0.0))
+    lamp = w.node(abi.RT_NODE_XZ_RECT, len(w.mat) - 1, p=lamp_p)
+    top.append((w.node(abi.RT_NODE_FLIP_FACE, -1, lamp, 0), None))
+    shapes = [w.node(abi.RT_NODE_XZ_RECT, -1, p=lamp_p)]
+    if rng.random() < 0.5:
+        c, r = rng.uniform(-2, 2, 3) * (1, 0.1, 1) + (0, 0.9, 0), float(rng.uniform(0.3, 0.7))
+        w.mat.append((abi.RT_MAT_DIELECTRIC, -1, (0, 0, 0), 1.5))
+        top.append((w.node(abi.RT_NODE_SPHERE, len(w.mat) - 1, p=(*c, r)), None))
+        shapes.append(w.node(abi.RT_NODE_SPHERE, -1, p=(*c, r)))
+    first = len(w.children)
+    w.children.extend(shapes)
+    lights = w.node(abi.RT_NODE_LIST, -1, first, len(shapes))
+    scene = w.finish(top, abi.RT_SKY_BACKGROUND)
+    scene.background = (0.0, 0.0, 0.0) if rng.random() < 0.5 else (0.2, 0.25, 0.3)
+    scene.lights_plus1 = lights + 1
+    return scene
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_world_importance_sampling_matches_oracle(seed, monkeypatch):
+    """Book 3's ray_color (parity with the reference unpinned: it has no such code) -- GPU against the oracle."""
+    scene = random_is_world(3000 + seed)
+    mk = lambda f: f((7, 3.5, 8), (0, 0.7, 0), (0, 1, 0), 32.0, 4.0 / 3.0, 0.0, 10.0, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    for flags in (abi.RT_RENDER_IMPORTANCE, 0):
+        p = abi.render_params(56, 42, 4, 50, seed=seed, flags=flags)
+        _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+        for set_min in (2, 1000):
+            monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+            c = lib.Context(0)
+            try:
+                c.upload(scene)
+                got, st = c.render(cam, p)
+            finally:
+                c.close()
+            assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, flags, set_min)
+            assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, flags, set_min)
