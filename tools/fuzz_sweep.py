@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One-off sweep of the random-world generators of tests/test_fuzz_worlds.py over many seeds (GPU against the oracle,
+bit for bit).  Usage: tools/fuzz_sweep.py <first seed> <count>"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_amd import abi, lib  # noqa: E402
+from tests import oracle_binding as ob  # noqa: E402
+from tests import test_fuzz_worlds as t  # noqa: E402
+first, count = int(sys.argv[1]), int(sys.argv[2])
+FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+bad = 0
+for seed in range(first, first + count):
+    for gen, name, flags_list in ((t.random_world, "graph", (0,)), (t.random_sphere_world, "spheres", (0,)),
+                                  (t.random_is_world, "importance", (abi.RT_RENDER_IMPORTANCE, 0))):
+        scene = gen(seed)
+        t0, t1 = ((0.0, 1.0), (0.25, 0.5), (0.0, 0.0), (-0.5, 1.5))[seed % 4] if name == "spheres" else (0.0, 1.0)
+        mk = lambda f: f((7 + seed % 3, 3.5, 8 - seed % 2), (0, 0.7, 0), (0, 1, 0), 32.0 + seed % 7, 4.0 / 3.0, 0.05 * (seed % 2), 10.0, t0, t1)
+        cam, ocam = mk(lib.camera), mk(ob.camera)
+        for flags in flags_list:
+            p = abi.render_params(48, 36, 3, 50, seed=seed, flags=flags)
+            _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+            want = fixed.astype(np.float64) / FRAC
+            oids = ob.first_hit(scene, ocam, 60, 45)
+            for set_min in (2, 1000):
+                os.environ["RT_SUBTREE_SET_MIN"] = str(set_min)
+                c = lib.Context(0)
+                try:
+                    c.upload(scene)
+                    got, st = c.render(cam, p)
+                    ids = c.first_hit(cam, 60, 45)
+                finally:
+                    c.close()
+                if st["rays"] != ost["rays"] or not np.array_equal(got, want) or not np.array_equal(ids, oids):
+                    bad += 1
+                    print(f"MISMATCH seed {seed} {name} flags {flags} set_min {set_min}: rays {st['rays']} vs {ost['rays']}, "
+                          f"pixels {int(np.any(got != want, axis=2).sum())}, ids {int((ids != oids).sum())}", flush=True)
+    if (seed - first) % 20 == 19:
+        print(f"... {seed - first + 1} seeds done, {bad} mismatches", flush=True)
+print(f"done: {count} seeds x 3 generators, {bad} mismatches")
