@@ -1024,10 +1024,11 @@ void scene_probe_dump() {
     unsigned long long h[16];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_total), sizeof(h)) != hipSuccess) return;
     static const char* names[] = {"other", "sphere", "moving", "xy", "xz", "yz", "box", "list", "bvh", "translate", "rotate", "medium"};
-    std::fprintf(stderr, "scene probe: wave-traces %llu  trips %llu (%.1f per trace)  lane fill %.3f\n", h[14], h[12],
-                 (double)h[12] / (double)(h[14] ? h[14] : 1), (double)h[13] / (64.0 * (double)(h[12] ? h[12] : 1)));
+    if (h[14] == 0) return;  // nothing rendered since the last dump
+    std::fprintf(stderr, "scene probe: wave-traces %llu; stack loop: trips %llu (%.1f per trace), lane fill %.3f\n", h[14], h[12],
+                 (double)h[12] / (double)h[14], h[12] ? (double)h[13] / (64.0 * (double)h[12]) : 0.0);
     for (int k = 0; k < 12; ++k)
-        if (h[k]) std::fprintf(stderr, "  entries %-9s %12llu  (%.2f per lane-trip)\n", names[k], h[k], (double)h[k] / (double)h[13]);
+        if (h[k]) std::fprintf(stderr, "  stack entries %-9s %12llu  (%.2f per lane-trip)\n", names[k], h[k], (double)h[k] / (double)(h[13] ? h[13] : 1));
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_total), z, sizeof(z));
     unsigned long long c[PS_COUNT];
