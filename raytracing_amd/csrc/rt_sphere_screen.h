@@ -182,7 +182,14 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     }
 
     const ScreenRay sr = screen_prepare(o, d, a);
-    uint32_t cnt = 0;
+    // A ray with a NaN or an infinity in it (book 3's light sampling produces them: the reference drops such samples at
+    // the end) has no meaningful float screen: the sign of a NaN is arbitrary, so it could name padding entries as
+    // candidates and drop real ones.  The reference's own comparisons all come out false for such a ray, which makes
+    // every object it tests a "hit" -- so the lane tests every member in double, in order, like the reference.
+    const double ray_sum = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
+    const bool finite_ray = ray_sum - ray_sum == 0.0;
+    uint32_t cnt = (on && !finite_ray) ? (uint32_t)CAND_CAP + 1u : 0u;
+    on = on && finite_ray;  // such lanes take no part in the screen; the overflow pass below serves them
     const uint64_t on_mask = ballot(on);
     pc.mark(SEC_PREP);
     if (__popcll(on_mask) <= SPARSE_MAX_RAYS) {
@@ -216,9 +223,11 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
                     if (cand != 0u) {
                         const int z = __clz((int)cand);
                         cand &= ~(0x80000000u >> z);
-                        if (cnt < (uint32_t)CAND_CAP)
-                            list[cnt * 64 + lane] = (uint16_t)(c * 2 * SPARSE_CHUNK_PAIRS + g * SCREEN_GROUP + z);
-                        ++cnt;
+                        const int member = c * 2 * SPARSE_CHUNK_PAIRS + g * SCREEN_GROUP + z;
+                        if (member < S.n) {  // never a padding entry, whatever the arithmetic said
+                            if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
+                            ++cnt;
+                        }
                     }
                 }
             }
@@ -247,8 +256,11 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
             if (cand != 0u) {
                 const int z = __clz((int)cand);
                 cand &= ~(0x80000000u >> z);
-                if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)(g * SCREEN_GROUP + z);
-                ++cnt;
+                const int member = g * SCREEN_GROUP + z;
+                if (member < S.n) {  // the padded half of an odd last pair is never a candidate
+                    if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
+                    ++cnt;
+                }
             }
         }
     }

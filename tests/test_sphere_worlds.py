@@ -429,3 +429,27 @@ def test_negative_radius_under_a_bvh_keeps_the_tree(ctx):
     flat.nodes[5]["p"][3] = -0.9  # the glass sphere directly in a list: no box involved, but still not a sphere world
     ctx.upload(flat)
     check_against_oracle(ctx, flat, 0.0, 1.0, abi.RT_KERNELS_SCENE_GRAPH)
+
+
+@pytest.mark.parametrize("world", ["nested", "cluster", "boxes"])
+def test_rays_with_nan_follow_the_reference_through_every_member(monkeypatch, world):
+    """A ray with a NaN in it makes every comparison of the reference false, so every object it tests counts as hit and
+    the last one tested wins.  The float screens mean nothing for such a ray (and a NaN's sign could name padding
+    entries): those lanes test every member in double, in order.  Camera origin = NaN makes every ray one."""
+    scene = {"nested": nested_world, "cluster": instanced_cluster_world, "boxes": lambda: box_field_world(1.0)}[world]()
+    cam, ocam = cam_for(0.0, 1.0), cam_for(0.0, 1.0, ob.camera)
+    cam.origin[0] = ocam.origin[0] = float("nan")
+    p = abi.render_params(32, 24, 2, 50, seed=5)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=8)
+    want_ids = ob.first_hit(scene, ocam, 16, 12)
+    monkeypatch.setenv("RT_SUBTREE_SET_MIN", "2")
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        got, st = c.render(cam, p)
+        ids = c.first_hit(cam, 16, 12)
+    finally:
+        c.close()
+    assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"]
+    assert np.array_equal(got, fixed.astype(np.float64) / FRAC)
+    assert np.array_equal(ids, want_ids)
