@@ -332,3 +332,65 @@ def test_random_world_importance_sampling_matches_oracle(seed, monkeypatch):
                 c.close()
             assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, flags, set_min)
             assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, flags, set_min)
+
+
+def random_big_set_world(seed):
+    """Large leaf sets: a BVH of 70-700 static spheres and boxes (several screening groups and chunks, odd counts),
+    by itself or instanced, next to a hollow glass sphere (negative radius), nested instances and a medium whose
+    boundary is a list; the camera of the test sometimes sits inside the cloud."""
+    rng = np.random.default_rng(seed)
+    w = WorldBuilder(rng)
+    top = [w.sphere((0, -1000, 0), 1000.0)]
+    n = int(rng.choice([70, 129, 257, 513, 700]))
+    kind = rng.choice(["spheres", "boxes", "mixed"])
+    leaves = []
+    for _ in range(n):
+        c = rng.uniform(-4, 4, 3) * (1, 0.35, 1) + (0, 1.6, 0)
+        if kind == "boxes" or (kind == "mixed" and rng.random() < 0.4):
+            lo = c - rng.uniform(0.05, 0.25, 3)
+            leaves.append(w.box(tuple(lo), tuple(lo + rng.uniform(0.1, 0.5, 3))))
+        else:
+            leaves.append(w.sphere(c, float(rng.uniform(0.05, 0.3))))
+    cloud = w.bvh(leaves)
+    top.append(w.instance(cloud) if rng.random() < 0.5 else cloud)
+    # a hollow glass ball: B1's trick of a second sphere with a negative radius inside the first
+    c = rng.uniform(-2, 2, 3) * (1, 0, 1) + (0, 0.7, 0)
+    w.mat.append((abi.RT_MAT_DIELECTRIC, -1, (0, 0, 0), 1.5))
+    glass = len(w.mat) - 1
+    top.append((w.node(abi.RT_NODE_SPHERE, glass, p=(*c, 0.7)), None))
+    top.append((w.node(abi.RT_NODE_SPHERE, glass, p=(*c, -0.6)), None))
+    # instances nested two deep around a leaf: up to four translate / rotate_y levels, the library's limit
+    top.append(w.instance(w.instance(w.random_leaf(moving=False))))
+    # a medium bounded by a list of two spheres
+    kids = [w.sphere(rng.uniform(-3, 3, 3) * (1, 0.1, 1) + (0, 0.9, 0), float(rng.uniform(0.5, 1.0))) for _ in range(2)]
+    first = len(w.children)
+    w.children.extend(i for i, _ in kids)
+    boundary = w.node(abi.RT_NODE_LIST, -1, first, 2)
+    w.mat.append((abi.RT_MAT_ISOTROPIC, w.solid(rng.uniform(0.2, 1.0, 3)), (0, 0, 0), 0.0))
+    top.append((w.node(abi.RT_NODE_MEDIUM, len(w.mat) - 1, boundary, 0, p=(-1.0 / float(rng.uniform(0.5, 3.0)),)), None))
+    return w.finish(top, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_big_set_world_matches_oracle(seed, monkeypatch):
+    scene = random_big_set_world(4000 + seed)
+    lookfrom = (7, 3.5, 8) if seed % 2 == 0 else (0.3, 1.5, 0.2)  # outside / inside the cloud
+    mk = lambda f: f(lookfrom, (0, 1.2, 0) if seed % 2 == 0 else (2, 1.4, 1), (0, 1, 0), 40.0, 4.0 / 3.0, 0.0, 10.0, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(56, 42, 4, 50, seed=seed)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    want_ids = ob.first_hit(scene, ocam, 72, 54)
+    for set_min in (64, 100000):
+        monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+        c = lib.Context(0)
+        try:
+            c.upload(scene)
+            got, st = c.render(cam, p)
+            ids = c.first_hit(cam, 72, 54)
+            c.set_exact_only(True)
+            exact, _ = c.render(cam, p)
+        finally:
+            c.close()
+        assert st["rays"] == ost["rays"], (seed, set_min)
+        assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, set_min)
+        assert np.array_equal(got, exact) and np.array_equal(ids, want_ids), (seed, set_min)
