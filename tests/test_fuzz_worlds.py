@@ -394,3 +394,70 @@ def test_random_big_set_world_matches_oracle(seed, monkeypatch):
         assert st["rays"] == ost["rays"], (seed, set_min)
         assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, set_min)
         assert np.array_equal(got, exact) and np.array_equal(ids, want_ids), (seed, set_min)
+
+
+def random_flat_list(seed):
+    """A book-1 world for the sphere-list kernels: 1 to ~1100 spheres (one or several screening chunks, odd counts),
+    overlapping, some hollow (negative radius), some huge, every material."""
+    from tests.conftest import make_sphere_scene
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 5, 31, 32, 33, 97, 256, 487, 511, 513, 1025, 1100]))
+    mats = [("lambertian", tuple(rng.uniform(0.1, 0.9, 3))), ("metal", tuple(rng.uniform(0.5, 1.0, 3)), float(rng.uniform(0, 1.2))),
+            ("dielectric", 1.5), ("lambertian", tuple(rng.uniform(0.1, 0.9, 3))), ("metal", (0.9, 0.9, 0.9), 0.0), ("dielectric", 2.4)]
+    spheres = []
+    if rng.random() < 0.8:
+        spheres.append((0.0, -1000.0, 0.0, 1000.0, 0))
+    while len(spheres) < n:
+        c = rng.uniform(-8, 8, 3) * (1, 0.15, 1) + (0, 0.5, 0)
+        r = float(rng.choice([0.05, 0.2, 0.2, 0.4, 1.0, 3.0]) * rng.uniform(0.8, 1.2))
+        m = int(rng.integers(0, len(mats)))
+        spheres.append((*c, r, m))
+        if mats[m][0] == "dielectric" and rng.random() < 0.3 and len(spheres) < n:
+            spheres.append((*c, -0.9 * r, m))  # hollow glass: B1R's trick
+    return make_sphere_scene(spheres[:n], mats, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])), (0.3, 0.4, 0.5)), rng
+
+
+def flat_list_case(seed):
+    """World, camera arguments and render parameters of one random book-1 case: odd image sizes, 1 to 130 samples per
+    pixel (from 100 on the pixel-by-pixel pass and the accumulation cache), sample offsets, shallow and deep paths,
+    cameras that may sit inside a sphere."""
+    scene, rng = random_flat_list(seed)
+    W, H = int(rng.integers(2, 70)), int(rng.integers(2, 50))
+    spp = int(rng.choice([1, 3, 8, 17, 104, 130]))
+    if spp > 100:
+        W, H = min(W, 40), min(H, 24)
+    depth = int(rng.choice([1, 5, 50]))
+    begin = int(rng.choice([0, 0, 7, 1000]))
+    lookfrom = tuple(rng.uniform(-9, 9, 3) * (1, 0.2, 1) + (0, 1.5, 0))
+    aperture = float(rng.choice([0.0, 0.1, 0.6]))
+    vfov = float(rng.choice([20.0, 60.0, 110.0]))
+    cam_args = (lookfrom, (0, 0.5, 0), (0, 1, 0), vfov, W / H, aperture, 6.0)
+    return scene, cam_args, abi.render_params(W, H, spp, depth, seed=seed * 7919 + 1, sample_begin=begin)
+
+
+def check_flat_list_case(seed):
+    scene, cam_args, p = flat_list_case(seed)
+    W, H = p.width, p.height
+    cam, ocam = lib.camera(*cam_args), ob.camera(*cam_args)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=16)
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        assert c.kernels_for(cam) == abi.RT_KERNELS_SPHERE_LIST
+        got, st = c.render(cam, p)
+        ids = c.first_hit(cam, W, H)
+        c.set_exact_only(True)
+        exact, se = c.render(cam, p)
+    finally:
+        c.close()
+    what = (seed, W, H, p.sample_count, p.max_depth, p.sample_begin)
+    assert st["rays"] == ost["rays"] == se["rays"] and st["samples"] == W * H * p.sample_count, what
+    assert np.array_equal(got, fixed.astype(np.float64) / FRAC), what
+    assert np.array_equal(got, exact), what
+    assert np.array_equal(ids, ob.first_hit(scene, ocam, W, H)), what
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_flat_list_matches_oracle(seed):
+    """The headline kernels on random lists, against the oracle and against their own exact-only mode."""
+    check_flat_list_case(6000 + seed)

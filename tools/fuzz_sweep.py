@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off sweep of the random-world generators of tests/test_fuzz_worlds.py over many seeds (GPU against the oracle,
-bit for bit).  Usage: tools/fuzz_sweep.py <first seed> <count>"""
+bit for bit): scene graphs, sphere worlds, importance sampling, large leaf sets and book-1 flat lists.  Usage: tools/fuzz_sweep.py <first seed> <count>"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,11 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
 bad = 0
 for seed in range(first, first + count):
+    try:
+        t.check_flat_list_case(seed)
+    except AssertionError as e:
+        bad += 1
+        print(f"MISMATCH seed {seed} flat list: {str(e)[:300]}", flush=True)
     for gen, name, flags_list in ((t.random_world, "graph", (0,)), (t.random_sphere_world, "spheres", (0,)),
                                   (t.random_is_world, "importance", (abi.RT_RENDER_IMPORTANCE, 0)),
                                   (t.random_big_set_world, "big sets", (0,))):
