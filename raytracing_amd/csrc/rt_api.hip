@@ -51,6 +51,7 @@ struct rt_context {
     // inside a graph, a BVH subtree of at least / at most this many static spheres and boxes is evaluated as a leaf set
     // (RT_SUBTREE_SET_MIN, RT_SUBTREE_SET_MAX; a minimum above the maximum turns sets off)
     int subtree_set_min = 64, subtree_set_max = 4096;
+    int cluster_min = 64;  // smallest sphere set that gets a two-level screen (RT_CLUSTER_MIN)
     SphereListDev spheres{};
     SceneDev graph{};
     std::vector<void*> scene_allocs;  // device memory owned by the current scene
@@ -407,9 +408,127 @@ static bool spheres_fit_float_screen(const rt_scene_desc* sc, const std::vector<
     return true;
 }
 
-static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, bool timed,
+// Two-level form of a set (SphereClustersDev) from its screening spheres `sph` (centre, radius >= 0, in set order) and
+// their float images `screen`.  Spheres with more than four times the median radius are "wide"; the others are split
+// at the median of their centres along the longest axis until at most CLUSTER_SIZE remain (left halves are whole
+// multiples of CLUSTER_SIZE, so all but one cluster are full).  A cluster's box encloses its members' screening
+// spheres and is widened by 2^-20 (B + O), B = largest coordinate of any box, O = cover = eight times that: 8 eps
+// for the float slab test (rt_screen_ops.h) and as much again for the reference's own rounding -- its discriminant,
+// computed in double, can accept a ray that passes a sphere at up to ~3e-8 |o - c| from its surface.
+// Leaves C.n_clusters == 0 (no two-level form) when the set is small or its coordinates are too large for the margin.
+struct ScreenSphere {
+    double c[3], r;
+};
+static int build_sphere_clusters(rt_context* ctx, const std::vector<ScreenSphere>& sph, const std::vector<SpherePair>& screen,
+                                 SphereClustersDev& C) {
+    C = SphereClustersDev{};
+    const int n = (int)sph.size();
+    if (n < ctx->cluster_min || n >= (int)NO_MEMBER) return RT_OK;
+    double extent = 0.0;
+    std::vector<double> radii((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        radii[(size_t)i] = sph[(size_t)i].r;
+        for (int k = 0; k < 3; ++k) extent = std::fmax(extent, std::fabs(sph[(size_t)i].c[k]) + sph[(size_t)i].r);
+    }
+    if (!(extent <= 1e6)) return RT_OK;
+    std::nth_element(radii.begin(), radii.begin() + n / 2, radii.end());
+    const double wide_from = 4.0 * radii[(size_t)n / 2];
+    std::vector<int> wide, rest;
+    for (int i = 0; i < n; ++i) (sph[(size_t)i].r > wide_from ? wide : rest).push_back(i);
+    if (rest.empty()) return RT_OK;
+
+    std::vector<std::vector<int>> clusters;
+    std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}};  // ranges of `rest` still to split
+    while (!todo.empty()) {
+        const auto [lo, hi] = todo.back();
+        todo.pop_back();
+        if (hi - lo <= (size_t)CLUSTER_SIZE) {
+            clusters.emplace_back(rest.begin() + (long)lo, rest.begin() + (long)hi);
+            std::sort(clusters.back().begin(), clusters.back().end());
+            continue;
+        }
+        double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = lo; i < hi; ++i)
+            for (int k = 0; k < 3; ++k) {
+                bmin[k] = std::fmin(bmin[k], sph[(size_t)rest[i]].c[k]);
+                bmax[k] = std::fmax(bmax[k], sph[(size_t)rest[i]].c[k]);
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k)
+            if (bmax[k] - bmin[k] > bmax[axis] - bmin[axis]) axis = k;
+        const size_t half = ((hi - lo) / 2 + CLUSTER_SIZE - 1) / CLUSTER_SIZE * CLUSTER_SIZE;
+        std::nth_element(rest.begin() + (long)lo, rest.begin() + (long)(lo + half), rest.begin() + (long)hi,
+                         [&](int a, int b) { return sph[(size_t)a].c[axis] < sph[(size_t)b].c[axis]; });
+        todo.push_back({lo + half, hi});
+        todo.push_back({lo, lo + half});
+    }
+
+    const int n_clusters = (int)clusters.size();
+    const double cover = 8.0 * extent, margin = 0x1p-20 * (extent + cover);
+    const int n_groups = (n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
+    std::vector<BoxPair> boxes((size_t)n_groups * (SCREEN_GROUP / 2));
+    std::memset(boxes.data(), 0, boxes.size() * sizeof(BoxPair));
+    SpherePair never;  // a padding slot never yields a candidate: q = -huge
+    for (int h = 0; h < 2; ++h) {
+        never.cx[h] = never.cy[h] = never.cz[h] = 0.0f;
+        never.k[h] = 3.0e38f;
+    }
+    std::vector<SpherePair> pairs((size_t)n_clusters * (CLUSTER_SIZE / 2), never);
+    std::vector<uint16_t> members((size_t)n_clusters * CLUSTER_SIZE, NO_MEMBER);
+    auto copy_half = [&](SpherePair& dst, int dst_half, int member) {
+        const SpherePair& src = screen[(size_t)member / 2];
+        dst.cx[dst_half] = src.cx[member & 1];
+        dst.cy[dst_half] = src.cy[member & 1];
+        dst.cz[dst_half] = src.cz[member & 1];
+        dst.k[dst_half] = src.k[member & 1];
+    };
+    for (int c = 0; c < n_clusters; ++c) {
+        BoxPair& bp = boxes[(size_t)c / 2];
+        for (int k = 0; k < 3; ++k) {
+            double lo = INFINITY, hi = -INFINITY;
+            for (int m : clusters[(size_t)c]) {
+                lo = std::fmin(lo, sph[(size_t)m].c[k] - sph[(size_t)m].r);
+                hi = std::fmax(hi, sph[(size_t)m].c[k] + sph[(size_t)m].r);
+            }
+            const double mid = 0.5 * (lo + hi);
+            const float mid_f = (float)mid;
+            const double hw = (0.5 * (hi - lo) + std::fabs(mid - (double)mid_f) + margin) * (1.0 + 1e-12);
+            float hw_f = (float)hw;
+            if ((double)hw_f < hw) hw_f = std::nextafterf(hw_f, INFINITY);
+            bp.mid[k][c & 1] = mid_f;
+            bp.hw[k][c & 1] = hw_f;
+        }
+        for (size_t j = 0; j < clusters[(size_t)c].size(); ++j) {
+            const int m = clusters[(size_t)c][j];
+            copy_half(pairs[(size_t)c * (CLUSTER_SIZE / 2) + j / 2], (int)(j & 1), m);
+            members[(size_t)c * CLUSTER_SIZE + j] = (uint16_t)m;
+        }
+    }
+    const int n_wide = (int)wide.size();
+    const int wide_groups = std::max(1, (n_wide + SCREEN_GROUP - 1) / SCREEN_GROUP);
+    std::vector<SpherePair> wide_pairs((size_t)wide_groups * (SCREEN_GROUP / 2), never);
+    std::vector<uint16_t> wide_members((size_t)wide_groups * SCREEN_GROUP, NO_MEMBER);
+    for (int j = 0; j < n_wide; ++j) {
+        copy_half(wide_pairs[(size_t)j / 2], j & 1, wide[(size_t)j]);
+        wide_members[(size_t)j] = (uint16_t)wide[(size_t)j];
+    }
+    int rc;
+    if ((rc = to_device(ctx, boxes, &C.boxes)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, pairs, &C.pairs)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, members, &C.members)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, wide_pairs, &C.wide_pairs)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, wide_members, &C.wide_members)) != RT_OK) return rc;
+    C.n_wide = n_wide;
+    C.cover = (float)cover;
+    if ((double)C.cover > cover) C.cover = std::nextafterf(C.cover, 0.0f);  // never claim more than the margin covers
+    C.n_clusters = n_clusters;
+    return RT_OK;
+}
+
+static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std::vector<int>& prims, bool timed, bool two_level,
                             SphereSetDev& S, double& sweep_lo, double& sweep_hi) {
     const int n = (int)prims.size();
+    std::vector<ScreenSphere> sph((size_t)n);
     const int n_pairs = (n + 1) / 2;
     const int n_chunks = std::max(1, (n_pairs + 255) / 256);
     std::vector<SpherePair> screen((size_t)n_chunks * 256);  // whole chunks: the sparse walk reads 4 pairs per lane
@@ -441,6 +560,7 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
             cz += 0.5 * dz;
             r = (std::fabs(nd.p[8]) + 0.5 * std::sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-6) + 1e-300;
         }
+        sph[(size_t)i] = ScreenSphere{{cx, cy, cz}, std::fabs(r)};
         const double cc = cx * cx + cy * cy + cz * cz, rr = r * r;
         const double k = cc - rr - 0x1p-18 * (cc + rr);
         // round k toward -inf so the float image never shrinks the margin
@@ -461,6 +581,7 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
     S.n_full_groups = n / SCREEN_GROUP;
     S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
     S.n_chunks = n_chunks;
+    if (two_level) return build_sphere_clusters(ctx, sph, screen, S.clusters);
     return RT_OK;
 }
 
@@ -520,7 +641,7 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
     SphereListDev& S = ctx->spheres;
     S = SphereListDev{};
     int rc;
-    if ((rc = build_sphere_set(ctx, sc, prims, timed, S.set, ctx->sweep_lo, ctx->sweep_hi)) != RT_OK) return rc;
+    if ((rc = build_sphere_set(ctx, sc, prims, timed, true, S.set, ctx->sweep_lo, ctx->sweep_hi)) != RT_OK) return rc;
     if ((rc = to_device(ctx, material_of, &S.material_of)) != RT_OK) return rc;
     if ((rc = to_device(ctx, mats, &S.materials)) != RT_OK) return rc;
     if (timed) {
@@ -664,7 +785,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             if (!spheres_fit_float_screen(sc, spheres)) continue;
             LeafSetDev sd{};
             double lo, hi;
-            int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, sd.spheres, lo, hi);
+            int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, false, sd.spheres, lo, hi);
             if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, cover, sd.boxes);
             if (rc != RT_OK) return rc;
             nodes[(size_t)idx].kind = DEV_NODE_LEAF_SET;  // p keeps the subtree's box
@@ -828,6 +949,7 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     ctx->blocks_per_cu_spheres = render_spheres_blocks_per_cu(false);
     ctx->blocks_per_cu_spheres_timed = render_spheres_blocks_per_cu(true);
     if (const char* s = std::getenv("RT_SPHERE_SET_MAX")) ctx->sphere_set_max = std::min(65535, std::max(0, std::atoi(s)));
+    if (const char* s = std::getenv("RT_CLUSTER_MIN")) ctx->cluster_min = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("RT_SUBTREE_SET_MIN")) ctx->subtree_set_min = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("RT_SUBTREE_SET_MAX")) ctx->subtree_set_max = std::min(65535, std::max(0, std::atoi(s)));
     if (const char* s = std::getenv("RT_PIXEL_PASS")) ctx->pixel_pass_min_samples = std::atoi(s) != 0 ? 0 : 0x7FFFFFFF;

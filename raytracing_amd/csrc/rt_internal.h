@@ -41,6 +41,33 @@ struct MaterialDev {
 
 constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
+#ifndef RT_CLUSTER_SIZE
+#define RT_CLUSTER_SIZE 8
+#endif
+constexpr int CLUSTER_SIZE = RT_CLUSTER_SIZE;  // spheres per cluster of the two-level screen (even, at most 32)
+constexpr int CLUSTER_CAP = 32;                // clusters per lane and walk held in LDS
+constexpr uint16_t NO_MEMBER = 0xFFFF;         // padding slot of a cluster
+
+// Screening image of axis-aligned boxes: two boxes interleaved component by component, like SpherePair.
+struct BoxPair {
+    float mid[3][2];  // centre per axis
+    float hw[3][2];   // half-width per axis, widened by the screen's error margin (rt_screen_ops.h), rounded up
+};
+// Two-level form of a large set.  The spheres are partitioned by position into clusters of at most CLUSTER_SIZE; the
+// wave screens the clusters' bounding boxes (slab test, scalar operands), then every lane screens only the members of
+// the clusters its own ray meets, reading their pair images with vector loads.  Spheres much larger than the others
+// ("wide": they would bloat any cluster) stay in a one-level image of their own.
+struct SphereClustersDev {
+    int32_t n_clusters;  // 0: the set has no two-level form
+    int32_t n_wide;
+    float cover;         // the box margins hold for rays whose origin coordinates are at most this in magnitude
+    int32_t pad;
+    const BoxPair* boxes;       // per cluster, padded to whole groups of SCREEN_GROUP
+    const SpherePair* pairs;    // CLUSTER_SIZE / 2 per cluster; padding slots never yield a candidate
+    const uint16_t* members;    // CLUSTER_SIZE per cluster: index in the set, NO_MEMBER for padding
+    const SpherePair* wide_pairs;   // padded to whole groups of SCREEN_GROUP / 2 pairs
+    const uint16_t* wide_members;   // n_wide indices in the set
+};
 
 struct SphereSetDev {
     int32_t n;         // spheres in list order (= object ids)
@@ -50,11 +77,7 @@ struct SphereSetDev {
     const SpherePair* screen;
     const SphereExact* exact;
     const SphereMotion* motion;  // book-2 sphere worlds only, else null
-};
-// Screening image of axis-aligned boxes: two boxes interleaved component by component, like SpherePair.
-struct BoxPair {
-    float mid[3][2];  // centre per axis
-    float hw[3][2];   // half-width per axis, widened by the screen's error margin (rt_box_screen.h), rounded up
+    SphereClustersDev clusters;
 };
 struct BoxSetDev {
     int32_t n;

@@ -6,6 +6,7 @@
 
 #include "rt_device_common.h"
 #include "rt_internal.h"
+#include "rt_screen_ops.h"
 
 namespace rtd {
 
@@ -30,87 +31,6 @@ struct ProbeClock {
 #endif
 enum { SEC_REFILL = 0, SEC_SCREEN_DENSE, SEC_SCREEN_SPARSE, SEC_EXACT, SEC_SHADE, SEC_PREP };
 
-// ---------------------------------------------------------------- screening pass
-//
-// For a ray o + t*d (d normalised to d^) and a sphere (c, r), real roots exist iff
-//     D = (oc.d^)^2 - |oc|^2 + r^2 >= 0,      oc = o - c.
-// Expanded so that each VALU op has exactly one per-sphere (scalar) operand:
-//     hb  = o.d^ - c.d^                                   3 fma
-//     acc = (m_o - |o|^2) - k + 2 o.c                     1 sub + 3 fma,  k = |c|^2 - r^2 - m_c
-//     q   = hb^2 + acc  = D + m_o + m_c                   1 fma
-// Every intermediate is bounded by (|o|+|c|)^2 + r^2, and with eps = 2^-24 the rounding of
-// the float inputs (o, d^, c, k) plus the 8 operations perturbs q by less than
-// 28 eps ((|o|+|c|)^2 + r^2) <= 56 eps (|o|^2 + |c|^2) + 28 eps r^2.  The margins
-//     m_o = 2^-18 |o|^2,   m_c = 2^-18 (|c|^2 + r^2)        (2^-18 = 64 eps)
-// exceed that, so a sphere whose reference discriminant (a double, relative error 1e-15)
-// is >= 0 always yields q > 0.  The sign bit of q is shifted into the mask: 0 = candidate.
-//
-// Issue rates measured on gfx950 (tools/ubench): a wave64 v_fma_f32 whose operands are all
-// VGPRs issues every ~2.2 cycles, but with an SGPR operand every ~4.2 cycles; v_pk_fma_f32
-// (two FMAs per lane) also issues every ~4.1 cycles and accepts an SGPR pair.  The 8 ops are
-// therefore done on PAIRS of spheres with packed math: 8 packed ops + 2 v_alignbit per pair,
-// 23 cycles per sphere per SIMD at 4 waves/SIMD against 31 for the unpacked form.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-struct ScreenRay {
-    f2 ndx, ndy, ndz;     // -d^, both halves equal
-    f2 p2ox, p2oy, p2oz;  // 2 o
-    f2 od;                // o . d^
-    f2 e;                 // m_o - |o|^2
-};
-
-__device__ __forceinline__ f2 splat(double x) {
-    const float f = (float)x;
-    return f2{f, f};
-}
-
-__device__ __forceinline__ ScreenRay screen_prepare(d3 o, d3 d, double a /* |d|^2 */) {
-    const double inv_len = 1.0 / sqrt(a);
-    const d3 dh = inv_len * d;
-    const double oo = len2(o);
-    ScreenRay s;
-    s.ndx = splat(-dh.x);
-    s.ndy = splat(-dh.y);
-    s.ndz = splat(-dh.z);
-    s.p2ox = splat(2.0 * o.x);
-    s.p2oy = splat(2.0 * o.y);
-    s.p2oz = splat(2.0 * o.z);
-    s.od = splat(dot(o, dh));
-    s.e = splat(oo * (0x1p-18 - 1.0));
-    return s;
-}
-
-typedef __attribute__((address_space(4))) SpherePair ConstSpherePair;
-
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// Screens two spheres given as packed operands; appends their sign bits (first sphere first) to mask.
-__device__ __forceinline__ uint32_t screen_pair_ops(const ScreenRay& r, f2 cx, f2 cy, f2 cz, f2 k, uint32_t mask) {
-    f2 hb = pk_fma(cx, r.ndx, r.od);
-    hb = pk_fma(cy, r.ndy, hb);
-    hb = pk_fma(cz, r.ndz, hb);
-    f2 acc = r.e - k;
-    acc = pk_fma(r.p2ox, cx, acc);
-    acc = pk_fma(r.p2oy, cy, acc);
-    acc = pk_fma(r.p2oz, cz, acc);
-    const f2 q = pk_fma(hb, hb, acc);
-    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q.x), 31);
-    return __builtin_amdgcn_alignbit(mask, __float_as_uint(q.y), 31);
-}
-// The pair *s read through the constant address space (scalar loads, SGPR-pair operands).
-__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const ConstSpherePair* s, uint32_t mask) {
-    return screen_pair_ops(r, f2{s->cx[0], s->cx[1]}, f2{s->cy[0], s->cy[1]}, f2{s->cz[0], s->cz[1]}, f2{s->k[0], s->k[1]}, mask);
-}
-// The pair p held in this lane's registers.
-__device__ __forceinline__ uint32_t screen_pair(const ScreenRay& r, const SpherePair& p, uint32_t mask) {
-    return screen_pair_ops(r, f2{p.cx[0], p.cx[1]}, f2{p.cy[0], p.cy[1]}, f2{p.cz[0], p.cz[1]}, f2{p.k[0], p.k[1]}, mask);
-}
-
-__device__ __forceinline__ f2 splat_from_lane(f2 v, int src_lane) {
-    const float f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v.x), src_lane));
-    return f2{f, f};
-}
-
 // Sparse waves.  When few lanes hold a ray (the end of a launch), walking all spheres with all 64 lanes
 // wastes most of the wave.  Instead the wave turns by 90 degrees: lane t keeps spheres 8t..8t+7 of a
 // 512-sphere chunk in registers, the rays are taken one at a time (their screening constants broadcast
@@ -121,8 +41,108 @@ __device__ __forceinline__ f2 splat_from_lane(f2 v, int src_lane) {
 #define RT_SPARSE_MAX_RAYS 32
 #endif
 constexpr int SPARSE_MAX_RAYS = RT_SPARSE_MAX_RAYS;  // dense walk: ~10k cycles per wave; this path: ~300 per ray and chunk
+#ifndef RT_SPARSE_MAX_RAYS_TWO_LEVEL
+#define RT_SPARSE_MAX_RAYS_TWO_LEVEL 8
+#endif
+constexpr int SPARSE_MAX_RAYS_TWO_LEVEL = RT_SPARSE_MAX_RAYS_TWO_LEVEL;  // sets with a two-level form: its walk is ~3x cheaper
 constexpr int ROW_WORDS = 17;        // 16 mask words per ray + 1 pad (bank spread)
 constexpr int SPARSE_CHUNK_PAIRS = 256;
+
+// ---------------------------------------------------------------- dense walks
+// All lanes x all n spheres of the pair image `image` (wave-uniform scalar loads; the image is padded to whole pairs
+// and, past them, readable up to a whole group).  Candidates are appended to the lane's list as set members:
+// position p is member p, or map[p] when MAPPED.  n_set = size of the set the members belong to.
+template <bool MAPPED>
+__device__ __forceinline__ void screen_all(const ScreenRay& sr, const SpherePair* image, const uint16_t* map, int n, int n_set,
+                                           bool on, uint16_t* list, int lane, uint32_t& cnt) {
+    // The screen image is immutable for the whole launch: address it through the constant
+    // address space so that the wave-uniform reads become scalar loads (SGPR operands).
+    const ConstSpherePair* sp = (const ConstSpherePair*)image;
+    const int n_full_groups = n / SCREEN_GROUP, n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
+    const int n_groups = n_full_groups + (n_tail_pairs > 0 ? 1 : 0);
+    for (int g = 0; g < n_groups; ++g) {
+        uint32_t mask = 0;
+        if (g < n_full_groups) {
+#pragma unroll
+            for (int jj = 0; jj < SCREEN_GROUP / 2; ++jj) mask = screen_pair(sr, sp + jj, mask);
+            sp += SCREEN_GROUP / 2;
+        } else {  // last, partial group: bits of absent spheres read "no candidate"
+            mask = ~0u;
+#pragma unroll 1
+            for (int jj = 0; jj < n_tail_pairs; ++jj) mask = screen_pair(sr, sp + jj, mask);
+            mask = ~(~mask << (SCREEN_GROUP - 2 * n_tail_pairs));
+        }
+        uint32_t cand = on ? ~mask : 0u;
+        while (ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int z = __clz((int)cand);
+                cand &= ~(0x80000000u >> z);
+                const int pos = g * SCREEN_GROUP + z;
+                if (pos < n) {  // the padded half of an odd last pair is never a candidate
+                    const int member = MAPPED ? (int)map[pos] : pos;
+                    if (member < n_set) {
+                        if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Two-level walk (SphereClustersDev): the wide spheres and the clusters' boxes wave-wide, then per lane the members of
+// the clusters its ray meets.  Every lane that is `on` must be covered by the box margins (br.covered).  `clist` =
+// CLUSTER_CAP*64 uint16 slots of the wave in LDS.  A lane that meets more than CLUSTER_CAP clusters reports more
+// candidates than the list holds, which sends it to the test of every member in double.  Candidates arrive in no
+// particular order.
+__device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const ScreenRay& sr, const BoxScreenRay& br, bool on,
+                                                uint16_t* list, uint16_t* clist, int lane, uint32_t& cnt) {
+    const SphereClustersDev& C = S.clusters;
+    uint32_t n_mine = 0;
+    const ConstBoxPair* bp = (const ConstBoxPair*)C.boxes;
+    const int n_groups = (C.n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
+    for (int g = 0; g < n_groups; ++g) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int jj = 0; jj < SCREEN_GROUP / 2; ++jj) mask = box_screen_pair(br, bp + jj, mask);
+        bp += SCREEN_GROUP / 2;
+        const int present = C.n_clusters - g * SCREEN_GROUP;  // the image is padded to whole groups
+        uint32_t cand = on ? ~mask : 0u;
+        if (present < SCREEN_GROUP) cand &= ~(0xFFFFFFFFu >> present);
+        while (ballot(cand != 0u) != 0ull) {
+            if (cand != 0u) {
+                const int z = __clz((int)cand);
+                cand &= ~(0x80000000u >> z);
+                if (n_mine < (uint32_t)CLUSTER_CAP) clist[n_mine * 64 + lane] = (uint16_t)(g * SCREEN_GROUP + z);
+                ++n_mine;
+            }
+        }
+    }
+    if (n_mine > (uint32_t)CLUSTER_CAP) {
+        cnt = (uint32_t)CAND_CAP + 1u;
+        n_mine = 0;
+    }
+    if (C.n_wide > 0) screen_all<true>(sr, C.wide_pairs, C.wide_members, C.n_wide, S.n, on, list, lane, cnt);
+    for (uint32_t i = 0; ballot(i < n_mine) != 0ull; ++i) {
+        if (i < n_mine) {
+            const int c = (int)clist[i * 64 + lane];
+            const SpherePair* mp = C.pairs + (size_t)c * (CLUSTER_SIZE / 2);
+            uint32_t mk = 0;
+#pragma unroll
+            for (int jj = 0; jj < CLUSTER_SIZE / 2; ++jj) mk = screen_pair(sr, mp[jj], mk);
+            uint32_t cand = ~mk << (32 - CLUSTER_SIZE);  // bit 31 = first member of the cluster
+            while (cand != 0u) {
+                const int z = __clz((int)cand);
+                cand &= ~(0x80000000u >> z);
+                const int member = (int)C.members[c * CLUSTER_SIZE + z];
+                if (member < S.n) {  // never a padding slot, whatever the arithmetic said
+                    if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
+                    ++cnt;
+                }
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------- exact pass
 struct SetHit {
@@ -191,8 +211,12 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     uint32_t cnt = (on && !finite_ray) ? (uint32_t)CAND_CAP + 1u : 0u;
     on = on && finite_ray;  // such lanes take no part in the screen; the overflow pass below serves them
     const uint64_t on_mask = ballot(on);
+    const bool two_level = S.clusters.n_clusters > 0;
+    BoxScreenRay br;
+    br.covered = false;
+    if (two_level) br = box_screen_prepare(o, d, S.clusters.cover);
     pc.mark(SEC_PREP);
-    if (__popcll(on_mask) <= SPARSE_MAX_RAYS) {
+    if (__popcll(on_mask) <= (two_level ? SPARSE_MAX_RAYS_TWO_LEVEL : SPARSE_MAX_RAYS)) {
         for (int c = 0; c < S.n_chunks; ++c) {
             const SpherePair* mine = S.screen + (size_t)c * SPARSE_CHUNK_PAIRS + (size_t)lane * 4;
             const SpherePair p0 = mine[0], p1 = mine[1], p2 = mine[2], p3 = mine[3];
@@ -234,43 +258,26 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
             __builtin_amdgcn_wave_barrier();
         }
         pc.mark(SEC_SCREEN_SPARSE);
+    } else if (two_level && ballot(on && !br.covered) == 0ull) {
+        screen_clusters(S, sr, br, on, list, (uint16_t*)rows, lane, cnt);
+        pc.mark(SEC_SCREEN_DENSE);
     } else {
-    // The screen image is immutable for the whole launch: address it through the constant
-    // address space so that the wave-uniform reads become scalar loads (SGPR operands).
-    const ConstSpherePair* sp = (const ConstSpherePair*)S.screen;
-    const int n_groups = S.n_full_groups + (S.n_tail_pairs > 0 ? 1 : 0);
-    for (int g = 0; g < n_groups; ++g) {
-        uint32_t mask = 0;
-        if (g < S.n_full_groups) {
-#pragma unroll
-            for (int jj = 0; jj < SCREEN_GROUP / 2; ++jj) mask = screen_pair(sr, sp + jj, mask);
-            sp += SCREEN_GROUP / 2;
-        } else {  // last, partial group: bits of absent spheres read "no candidate"
-            mask = ~0u;
-#pragma unroll 1
-            for (int jj = 0; jj < S.n_tail_pairs; ++jj) mask = screen_pair(sr, sp + jj, mask);
-            mask = ~(~mask << (SCREEN_GROUP - 2 * S.n_tail_pairs));
-        }
-        uint32_t cand = on ? ~mask : 0u;
-        while (ballot(cand != 0u) != 0ull) {
-            if (cand != 0u) {
-                const int z = __clz((int)cand);
-                cand &= ~(0x80000000u >> z);
-                const int member = g * SCREEN_GROUP + z;
-                if (member < S.n) {  // the padded half of an odd last pair is never a candidate
-                    if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
-                    ++cnt;
-                }
-            }
-        }
-    }
-    pc.mark(SEC_SCREEN_DENSE);
+        screen_all<false>(sr, S.screen, nullptr, S.n, S.n, on, list, lane, cnt);
+        pc.mark(SEC_SCREEN_DENSE);
     }
 
     const bool overflow = cnt > (uint32_t)CAND_CAP;
     const uint32_t my_n = overflow ? 0u : cnt;
+    // The reference tests the members in list order and accepts a root equal to the closest so far, so of two members
+    // hit at exactly the same t the later one wins.  The candidates of the two-level walk come in no particular order:
+    // the same rule stated on the indices gives the same winner for any order.
     for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
-        if (i < my_n) exact((int)list[i * 64 + lane], h);
+        if (i < my_n) {
+            const int j = (int)list[i * 64 + lane];
+            SetHit one{h.t, -1};
+            exact(j, one);
+            if (one.id >= 0 && (one.t < h.t || j > h.id)) h = one;
+        }
     }
     if (ballot(overflow) != 0ull) {
         if (overflow) {  // more candidates than slots: test the whole list in double
