@@ -42,7 +42,7 @@ struct MaterialDev {
 constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
 #ifndef RT_CLUSTER_SIZE
-#define RT_CLUSTER_SIZE 8
+#define RT_CLUSTER_SIZE 16
 #endif
 constexpr int CLUSTER_SIZE = RT_CLUSTER_SIZE;  // spheres per cluster of the two-level screen (even, at most 32)
 constexpr int CLUSTER_CAP = 32;                // clusters per lane and walk held in LDS

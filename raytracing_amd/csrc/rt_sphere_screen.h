@@ -22,14 +22,16 @@ struct ProbeClock {
         sec[k] += now - last;
         last = now;
     }
+    __device__ __forceinline__ void add(int k, uint64_t v) { sec[k] += v; }
 };
 #else
 struct ProbeClock {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void add(int, uint64_t) {}
 };
 #endif
-enum { SEC_REFILL = 0, SEC_SCREEN_DENSE, SEC_SCREEN_SPARSE, SEC_EXACT, SEC_SHADE, SEC_PREP };
+enum { SEC_REFILL = 0, SEC_SCREEN_DENSE, SEC_SCREEN_SPARSE, SEC_EXACT, SEC_SHADE, SEC_PREP, SEC_SCREEN_MEMBERS };
 
 // Sparse waves.  When few lanes hold a ray (the end of a launch), walking all spheres with all 64 lanes
 // wastes most of the wave.  Instead the wave turns by 90 degrees: lane t keeps spheres 8t..8t+7 of a
@@ -96,7 +98,7 @@ __device__ __forceinline__ void screen_all(const ScreenRay& sr, const SpherePair
 // candidates than the list holds, which sends it to the test of every member in double.  Candidates arrive in no
 // particular order.
 __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const ScreenRay& sr, const BoxScreenRay& br, bool on,
-                                                uint16_t* list, uint16_t* clist, int lane, uint32_t& cnt) {
+                                                uint16_t* list, uint16_t* clist, int lane, uint32_t& cnt, ProbeClock& pc) {
     const SphereClustersDev& C = S.clusters;
     uint32_t n_mine = 0;
     const ConstBoxPair* bp = (const ConstBoxPair*)C.boxes;
@@ -123,7 +125,9 @@ __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const Scr
         n_mine = 0;
     }
     if (C.n_wide > 0) screen_all<true>(sr, C.wide_pairs, C.wide_members, C.n_wide, S.n, on, list, lane, cnt);
+    pc.mark(SEC_SCREEN_DENSE);
     for (uint32_t i = 0; ballot(i < n_mine) != 0ull; ++i) {
+        pc.add(7, 1);
         if (i < n_mine) {
             const int c = (int)clist[i * 64 + lane];
             const SpherePair* mp = C.pairs + (size_t)c * (CLUSTER_SIZE / 2);
@@ -259,8 +263,8 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
         }
         pc.mark(SEC_SCREEN_SPARSE);
     } else if (two_level && ballot(on && !br.covered) == 0ull) {
-        screen_clusters(S, sr, br, on, list, (uint16_t*)rows, lane, cnt);
-        pc.mark(SEC_SCREEN_DENSE);
+        screen_clusters(S, sr, br, on, list, (uint16_t*)rows, lane, cnt, pc);
+        pc.mark(SEC_SCREEN_MEMBERS);
     } else {
         screen_all<false>(sr, S.screen, nullptr, S.n, S.n, on, list, lane, cnt);
         pc.mark(SEC_SCREEN_DENSE);

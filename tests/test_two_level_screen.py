@@ -1,0 +1,106 @@
+"""The two-level screen of the sphere-list kernels (clusters of nearby spheres behind a slab test of the clusters'
+boxes) must never change a result: with it, without it (RT_CLUSTER_MIN above the world's size) and with no float screen
+at all (exact-only) the sums, ray counts and first-hit ids are those of the oracle, bit for bit -- including the cases
+the walk treats specially: spheres hit at exactly the same t (the later one in list order wins, whatever order the
+candidates arrive in), rays the box margins do not cover (far origins, axis-parallel directions), a ray that meets
+more clusters than a lane can hold, and worlds too large for the margins."""
+import numpy as np
+import pytest
+
+from raytracing_amd import abi, lib
+from tests import oracle_binding as ob
+from tests.conftest import CAM_C2, gold, make_sphere_scene
+
+pytestmark = pytest.mark.gpu
+FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+MATS = [("lambertian", (0.5, 0.5, 0.5)), ("metal", (0.8, 0.7, 0.6), 0.1), ("dielectric", 1.5), ("lambertian", (0.2, 0.6, 0.3))]
+
+
+def render_all_ways(monkeypatch, scene, cam_args, p, fh):
+    """GPU results with the two-level walk, with the one-level walk and with no screen; oracle results."""
+    cam, ocam = lib.camera(*cam_args), ob.camera(*cam_args)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=16)
+    want, want_ids = fixed.astype(np.float64) / FRAC, ob.first_hit(scene, ocam, *fh)
+    out = {}
+    for name, cluster_min, exact_only in (("two-level", 8, False), ("one-level", 1 << 20, False), ("exact", 8, True)):
+        monkeypatch.setenv("RT_CLUSTER_MIN", str(cluster_min))
+        c = lib.Context(0)
+        try:
+            c.upload(scene)
+            assert c.kernels_for(cam) == abi.RT_KERNELS_SPHERE_LIST
+            c.set_exact_only(exact_only)
+            got, st = c.render(cam, p)
+            out[name] = (got, st, c.first_hit(cam, *fh))
+        finally:
+            c.close()
+    for name, (got, st, ids) in out.items():
+        assert st["rays"] == ost["rays"], name
+        assert np.array_equal(got, want), name
+        assert np.array_equal(ids, want_ids), name
+    return out
+
+
+def grid_world(n_side=12, copies=1, scale=1.0, ground=True):
+    """n_side x n_side small spheres on a plane, every sphere present `copies` times at different list positions."""
+    rng = np.random.default_rng(5)
+    spheres = [(0.0, -1000.0 * scale, 0.0, 1000.0 * scale, 0)] if ground else []
+    cells = [(i, j) for i in range(n_side) for j in range(n_side)]
+    for rep in range(copies):
+        for (i, j) in (cells if rep % 2 == 0 else cells[::-1]):
+            r = np.random.default_rng(1000 * i + j)
+            c = ((i - n_side / 2 + 0.9 * r.random()) * scale, 0.2 * scale, (j - n_side / 2 + 0.9 * r.random()) * scale)
+            spheres.append((*c, 0.2 * scale, (i + j + rep) % len(MATS)))
+    return make_sphere_scene(spheres, MATS, abi.RT_SKY_GRADIENT, (0, 0, 0))
+
+
+def test_config_2_world_all_ways(monkeypatch):
+    scene = abi.load_scene(gold("scene_c2.rtsc"))
+    out = render_all_ways(monkeypatch, scene, CAM_C2, abi.render_params(120, 80, 12, 50, seed=3), (150, 100))
+    assert out["two-level"][1]["overflow_rays"] == 0
+
+
+def test_coincident_spheres_later_one_wins(monkeypatch):
+    """Every sphere three times in the list, with different materials: all three are hit at the same t, the reference
+    keeps the last.  The copies sit in different slots of a cluster (or in different clusters)."""
+    scene = grid_world(copies=3)
+    render_all_ways(monkeypatch, scene, ((9, 2.5, 7), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.05, 10.0),
+                    abi.render_params(90, 60, 6, 50, seed=11), (120, 80))
+
+
+def test_axis_parallel_and_far_rays_fall_back(monkeypatch):
+    """A camera looking straight down an axis with no lens (direction components exactly 0 along the centre row and
+    column) and a camera farther away than the margins cover: such waves take the one-level walk."""
+    scene = grid_world(ground=False)
+    render_all_ways(monkeypatch, scene, ((0, 0.2, 30), (0, 0.2, 0), (0, 1, 0), 25.0, 1.0, 0.0, 30.0),
+                    abi.render_params(65, 65, 3, 50, seed=2), (65, 65))
+    far = 1.0e4  # extent of the world ~6, cover ~50
+    render_all_ways(monkeypatch, scene, ((far, 0.3 * far, 0.5 * far), (0, 0, 0), (0, 1, 0), 0.06, 1.5, 0.0, far),
+                    abi.render_params(60, 40, 3, 50, seed=2), (60, 40))
+
+
+def test_ray_through_more_clusters_than_a_lane_holds(monkeypatch):
+    """600 touching spheres in a row, seen along the row: the central rays meet every cluster's box (more than the 32
+    a lane can note), so those lanes test the whole list in double."""
+    spheres = [(0.0, 0.0, -0.25 * i, 0.15, i % len(MATS)) for i in range(600)]
+    scene = make_sphere_scene(spheres, MATS, abi.RT_SKY_GRADIENT, (0, 0, 0))
+    out = render_all_ways(monkeypatch, scene, ((0.02, 0.01, 6), (0, 0, -50), (0, 1, 0), 8.0, 1.0, 0.0, 10.0),
+                          abi.render_params(48, 48, 2, 50, seed=4), (48, 48))
+    assert out["two-level"][1]["overflow_rays"] > 0
+
+
+@pytest.mark.parametrize("scale", [1.0e-3, 1.0e3, 1.0e7])
+def test_scaled_worlds(monkeypatch, scale):
+    """The margins scale with the world; beyond 1e6 the set has no two-level form and the flat walk serves it."""
+    scene = grid_world(scale=scale)
+    s = scale
+    render_all_ways(monkeypatch, scene, ((9 * s, 2.5 * s, 7 * s), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.05 * s, 10.0 * s),
+                    abi.render_params(72, 48, 4, 50, seed=8), (72, 48))
+
+
+def test_wide_spheres_only_world(monkeypatch):
+    """Radii spread over four decades: many spheres count as wide and keep their one-level image."""
+    rng = np.random.default_rng(21)
+    spheres = [(*rng.uniform(-6, 6, 3), float(10.0 ** rng.uniform(-2, 0.5)), int(rng.integers(0, 4))) for _ in range(200)]
+    scene = make_sphere_scene(spheres, MATS, abi.RT_SKY_GRADIENT, (0, 0, 0))
+    render_all_ways(monkeypatch, scene, ((14, 3, 9), (0, 0, 0), (0, 1, 0), 50.0, 1.5, 0.1, 12.0),
+                    abi.render_params(72, 48, 4, 50, seed=9), (72, 48))

@@ -44,8 +44,9 @@ print(f"wave-iterations after dry / total: {p[:,4].sum() / p[:,3].sum():.4f}")
 edges = np.linspace(np.median(tq[p[:, 1] > 0]), tx.max(), 13)
 alive = [(tx > e).sum() for e in edges]
 print("waves alive after dry:", " ".join(f"{e - edges[0]:.2f}ms:{a}" for e, a in zip(edges, alive)))
-sec = p[:, 8:14].sum(axis=0)
-names = ["refill+camera", "screen dense", "screen sparse", "exact", "shade", "screen prep"]
+sec = p[:, 8:15].sum(axis=0)
+names = ["refill+camera", "screen dense", "screen sparse", "exact", "shade", "screen prep", "screen members"]
 print("wave time by section: " + "  ".join(f"{n} {100 * v / sec.sum():.1f}%" for n, v in zip(names, sec)))
 print(f"cycles per wave trip: {sec.sum() / p[:, 3].sum():.0f} (clock64 ticks), sections: " + " ".join(f"{v / p[:, 3].sum():.0f}" for v in sec))
 ctx.close()
+print(f"member-screen rounds per wave trip: {p[:, 15].sum() / p[:, 3].sum():.2f}")
