@@ -464,6 +464,7 @@ static int build_sphere_clusters(rt_context* ctx, const std::vector<ScreenSphere
     }
 
     const int n_clusters = (int)clusters.size();
+    if (n_clusters > 1024) return RT_OK;  // a queue item of the walk names a cluster in 10 bits
     const double cover = 8.0 * extent, margin = 0x1p-20 * (extent + cover);
     const int n_groups = (n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
     std::vector<BoxPair> boxes((size_t)n_groups * (SCREEN_GROUP / 2));

@@ -45,7 +45,6 @@ constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
 #define RT_CLUSTER_SIZE 16
 #endif
 constexpr int CLUSTER_SIZE = RT_CLUSTER_SIZE;  // spheres per cluster of the two-level screen (even, at most 32)
-constexpr int CLUSTER_CAP = 32;                // clusters per lane and walk held in LDS
 constexpr uint16_t NO_MEMBER = 0xFFFF;         // padding slot of a cluster
 
 // Screening image of axis-aligned boxes: two boxes interleaved component by component, like SpherePair.

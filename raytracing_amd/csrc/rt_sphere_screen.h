@@ -92,15 +92,30 @@ __device__ __forceinline__ void screen_all(const ScreenRay& sr, const SpherePair
     }
 }
 
-// Two-level walk (SphereClustersDev): the wide spheres and the clusters' boxes wave-wide, then per lane the members of
-// the clusters its ray meets.  Every lane that is `on` must be covered by the box margins (br.covered).  `clist` =
-// CLUSTER_CAP*64 uint16 slots of the wave in LDS.  A lane that meets more than CLUSTER_CAP clusters reports more
-// candidates than the list holds, which sends it to the test of every member in double.  Candidates arrive in no
-// particular order.
+// Two-level walk (SphereClustersDev): the wide spheres and the clusters' boxes wave-wide; every (ray, cluster) meeting
+// becomes an item of a wave-wide queue in LDS, and the items are then screened 64 at a time, one per lane, whichever
+// lane the ray belongs to -- the rays' screening constants travel by lane permutation, candidates go to the owning
+// ray's list through a counter in LDS.  (Left to its own ray alone, every lane would wait for the ray that meets the
+// most clusters: ~4 rounds against ~2 on the One-Weekend final scene.)  Every lane that is `on` must be covered by the
+// box margins (br.covered).  `rows` = the wave's ROW_WORDS*64 words: the queue, then the 64 counters.  A wave whose
+// queue is full sends the rays that still have clusters to note to the test of every member in double.  Candidates
+// arrive in no particular order.
+constexpr int ITEM_CAP = 2048;         // items per wave and walk
+constexpr int ITEM_CLUSTER_BITS = 10;  // an item = lane << 10 | cluster: at most 1024 clusters
+static_assert(ITEM_CAP * 2 + 64 * 4 <= ROW_WORDS * 64 * 4, "the queue and the counters share the rows of the sparse walk");
+
+__device__ __forceinline__ f2 splat_from_lane_of(f2 v, int src_lane) {  // src_lane may differ from lane to lane
+    const float f = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)__float_as_uint(v.x)));
+    return f2{f, f};
+}
+
 __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const ScreenRay& sr, const BoxScreenRay& br, bool on,
-                                                uint16_t* list, uint16_t* clist, int lane, uint32_t& cnt, ProbeClock& pc) {
+                                                uint16_t* list, uint32_t* rows, int lane, uint32_t& cnt, ProbeClock& pc) {
     const SphereClustersDev& C = S.clusters;
-    uint32_t n_mine = 0;
+    uint16_t* items = (uint16_t*)rows;
+    uint32_t* counts = rows + ITEM_CAP / 2;
+    uint32_t n_items = 0;  // the same in every lane
+    bool dropped = false;
     const ConstBoxPair* bp = (const ConstBoxPair*)C.boxes;
     const int n_groups = (C.n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
     for (int g = 0; g < n_groups; ++g) {
@@ -111,41 +126,60 @@ __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const Scr
         const int present = C.n_clusters - g * SCREEN_GROUP;  // the image is padded to whole groups
         uint32_t cand = on ? ~mask : 0u;
         if (present < SCREEN_GROUP) cand &= ~(0xFFFFFFFFu >> present);
-        while (ballot(cand != 0u) != 0ull) {
+        for (uint64_t busy = ballot(cand != 0u); busy != 0ull; busy = ballot(cand != 0u)) {
+            const bool room = n_items + 64u <= (uint32_t)ITEM_CAP;
             if (cand != 0u) {
                 const int z = __clz((int)cand);
                 cand &= ~(0x80000000u >> z);
-                if (n_mine < (uint32_t)CLUSTER_CAP) clist[n_mine * 64 + lane] = (uint16_t)(g * SCREEN_GROUP + z);
-                ++n_mine;
+                const uint32_t before_me = __builtin_amdgcn_mbcnt_hi((uint32_t)(busy >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)busy, 0u));
+                if (room) items[n_items + before_me] = (uint16_t)((lane << ITEM_CLUSTER_BITS) | (g * SCREEN_GROUP + z));
+                else dropped = true;
             }
+            if (room) n_items += (uint32_t)__popcll(busy);
         }
     }
-    if (n_mine > (uint32_t)CLUSTER_CAP) {
-        cnt = (uint32_t)CAND_CAP + 1u;
-        n_mine = 0;
-    }
+    if (dropped) cnt = (uint32_t)CAND_CAP + 1u;
     if (C.n_wide > 0) screen_all<true>(sr, C.wide_pairs, C.wide_members, C.n_wide, S.n, on, list, lane, cnt);
+    counts[lane] = cnt;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     pc.mark(SEC_SCREEN_DENSE);
-    for (uint32_t i = 0; ballot(i < n_mine) != 0ull; ++i) {
+    for (uint32_t base = 0; base < n_items; base += 64u) {
         pc.add(7, 1);
-        if (i < n_mine) {
-            const int c = (int)clist[i * 64 + lane];
+        const bool live = base + (uint32_t)lane < n_items;
+        const uint32_t item = live ? (uint32_t)items[base + lane] : 0u;
+        const int ray = (int)(item >> ITEM_CLUSTER_BITS), c = (int)(item & ((1u << ITEM_CLUSTER_BITS) - 1u));
+        ScreenRay rl;  // the constants of the item's ray (all lanes take part in the permutations)
+        rl.ndx = splat_from_lane_of(sr.ndx, ray);
+        rl.ndy = splat_from_lane_of(sr.ndy, ray);
+        rl.ndz = splat_from_lane_of(sr.ndz, ray);
+        rl.p2ox = splat_from_lane_of(sr.p2ox, ray);
+        rl.p2oy = splat_from_lane_of(sr.p2oy, ray);
+        rl.p2oz = splat_from_lane_of(sr.p2oz, ray);
+        rl.od = splat_from_lane_of(sr.od, ray);
+        rl.e = splat_from_lane_of(sr.e, ray);
+        if (live) {
             const SpherePair* mp = C.pairs + (size_t)c * (CLUSTER_SIZE / 2);
             uint32_t mk = 0;
 #pragma unroll
-            for (int jj = 0; jj < CLUSTER_SIZE / 2; ++jj) mk = screen_pair(sr, mp[jj], mk);
+            for (int jj = 0; jj < CLUSTER_SIZE / 2; ++jj) mk = screen_pair(rl, mp[jj], mk);
             uint32_t cand = ~mk << (32 - CLUSTER_SIZE);  // bit 31 = first member of the cluster
             while (cand != 0u) {
                 const int z = __clz((int)cand);
                 cand &= ~(0x80000000u >> z);
                 const int member = (int)C.members[c * CLUSTER_SIZE + z];
                 if (member < S.n) {  // never a padding slot, whatever the arithmetic said
-                    if (cnt < (uint32_t)CAND_CAP) list[cnt * 64 + lane] = (uint16_t)member;
-                    ++cnt;
+                    const uint32_t slot = __hip_atomic_fetch_add(&counts[ray], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (slot < (uint32_t)CAND_CAP) list[slot * 64 + ray] = (uint16_t)member;
                 }
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    cnt = counts[lane];
 }
 
 // ---------------------------------------------------------------- exact pass
@@ -263,7 +297,7 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
         }
         pc.mark(SEC_SCREEN_SPARSE);
     } else if (two_level && ballot(on && !br.covered) == 0ull) {
-        screen_clusters(S, sr, br, on, list, (uint16_t*)rows, lane, cnt, pc);
+        screen_clusters(S, sr, br, on, list, rows, lane, cnt, pc);
         pc.mark(SEC_SCREEN_MEMBERS);
     } else {
         screen_all<false>(sr, S.screen, nullptr, S.n, S.n, on, list, lane, cnt);
