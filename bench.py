@@ -36,6 +36,33 @@ def algorithmic_flop(n_objects, rays, samples):
     return rays * (n_objects * 23.0 + 60.0) + samples * 40.0
 
 
+def profiled_execution(n_objects):
+    """What k_render_spheres executes per ray, from the newest committed rocprofv3 counter summary of this command
+    (profiles/*_bench_c2.json, tools/profile_bench.sh): vector flops as the hardware counts them
+    (SQ_INSTS_VALU_FLOPS_FP32 + _FP64 + _FP64_TRANS: flop per lane of every VALU wave-instruction, x 64 lanes whether or
+    not a lane is active), VALU issue utilisation and the share of active lanes.  The kernel does not walk the flat
+    list sphere by sphere (two-level screen), so its roofline is priced on these executed flops, not on the
+    reference algorithm's.  None when no summary holds the counters."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_c2.json"))):
+        try:
+            with open(path) as fp:
+                prof = json.load(fp)
+            line = prof["bench_line_under_profiler"]
+            c, d = prof["counters_per_launch"], prof["derived"]
+            if line["config"]["objects"] != n_objects:
+                continue
+            rays = line["rays_per_sample"] * line["config"]["width"] * line["config"]["height"] * line["config"]["spp"]
+            flop = 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP32"] + c["SQ_INSTS_VALU_FLOPS_FP64"] + c["SQ_INSTS_VALU_FLOPS_FP64_TRANS"])
+            best = {"flop_per_ray": flop / rays, "fp64_share": 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP64"] + c["SQ_INSTS_VALU_FLOPS_FP64_TRANS"]) / flop,
+                    "valu_issue_utilisation": d["valu_busy_estimate"], "lanes_active": d["valu_lane_utilisation"],
+                    "source": os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return best
+
+
 def profiled_traffic(width, height, spp, depth):
     """HBM-side bytes per launch of k_render_spheres from the newest committed rocprofv3 counter summary
     (profiles/*_bench_c2.json: FETCH_SIZE + WRITE_SIZE passes of this same command, see tools/profile_bench.sh),
@@ -245,8 +272,11 @@ def main():
         # (with several frames in flight launches overlap each other, so the wall time per step is used
         # instead: an upper bound on the kernel's time, i.e. a lower bound on the fraction)
         k_ms = st["kernel_ms"] / max(1, st["kernel_launches"]) if n_slots == 1 else dt / args.steps * 1e3
-        flop_per_launch = algorithmic_flop(n_objects, st["rays"], st["samples"]) / max(1, st["kernel_launches"])
-        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        launches = max(1, st["kernel_launches"])
+        reference_flop = algorithmic_flop(n_objects, st["rays"], st["samples"]) / launches
+        executed = profiled_execution(n_objects)
+        flop_per_launch = executed["flop_per_ray"] * st["rays"] / launches if executed else None
+        achieved = flop_per_launch / (k_ms * 1e-3) / 1e12 if executed and k_ms > 0 else None
         traffic = profiled_traffic(W, H, spp, args.depth)
         out = {
             "metric": "Msamples/sec (paths x spp / s), One-Weekend final scene",
@@ -260,14 +290,26 @@ def main():
                        "frames_in_flight": n_slots},
             "mrays_per_s": rays / dt / 1e6, "rays_per_sample": rays / max(1, samples), "nan_samples": bad,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic["bytes"] if traffic else None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved is not None else None,
+                         "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "k_render_spheres", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch,
-                         "note": "FP32 vector roofline; flop = reference algorithm (flat list, 23 flop per "
-                                 "sphere test); traffic = L2 memory-side bytes per launch from the committed "
-                                 "counter passes (64-bit accumulation atomics, absorbed by the Infinity Cache; "
-                                 "algorithmic bytes are the 23 MB frame)"},
+                         "flop_source": executed["source"] if executed else None,
+                         "fp64_share_of_flop": executed["fp64_share"] if executed else None,
+                         "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,
+                         "lanes_active": executed["lanes_active"] if executed else None,
+                         "reference_algorithm_tflops": reference_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None,
+                         "note": "FP32 vector roofline.  The kernel screens the list through a two-level "
+                                 "structure, so flop = EXECUTED vector flops (hardware counters of the committed "
+                                 "profile of this command, per ray, x this run's rays; 64 lanes per "
+                                 "wave-instruction), not the flat-list price of the reference algorithm "
+                                 "(reference_algorithm_tflops = what that price would give, context only).  "
+                                 "The kernel is bound by VALU issue (valu_issue_utilisation: share of cycles a "
+                                 "SIMD issues a vector instruction), most of it double-precision, integer and "
+                                 "control work that the flop count does not see.  traffic = L2 memory-side "
+                                 "bytes per launch from the committed counter passes (64-bit accumulation "
+                                 "atomics, absorbed by the Infinity Cache; algorithmic bytes are the 23 MB frame)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path)

@@ -76,6 +76,12 @@ def main():
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         # share of cycles in which a SIMD issues a VALU instruction, pricing one at the measured ~4.1 cycles
         derived["valu_busy_estimate"] = min(1.0, derived["valu_wave_instr_per_cycle_per_simd"] * 4.1)
+    if "SQ_INSTS_VALU_FLOPS_FP32" in c and "SQ_INSTS_VALU_FLOPS_FP64" in c:
+        # the counters give flop per lane of every VALU wave-instruction; a wave-instruction occupies all 64 lanes
+        flop = 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP32"] + c["SQ_INSTS_VALU_FLOPS_FP64"] + c.get("SQ_INSTS_VALU_FLOPS_FP64_TRANS", 0.0))
+        derived["executed_vector_flop_per_launch"] = flop
+        derived["executed_vector_TFLOPs"] = flop / (avg_ms * 1e-3) / 1e12
+        derived["executed_flop_fp64_share"] = 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP64"] + c.get("SQ_INSTS_VALU_FLOPS_FP64_TRANS", 0.0)) / flop
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
         derived["l1_requests_served_without_l2"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
 
