@@ -44,7 +44,8 @@ for seed in range(first, first + count):
                 if st["rays"] != ost["rays"] or not np.array_equal(got, want) or not np.array_equal(ids, oids):
                     bad += 1
                     print(f"MISMATCH seed {seed} {name} flags {flags} set_min {set_min}: rays {st['rays']} vs {ost['rays']}, "
-                          f"pixels {int(np.any(got != want, axis=2).sum())}, ids {int((ids != oids).sum())}", flush=True)
+                          f"pixels {int(np.any(got != want, axis=2).sum())} (largest difference {np.abs(got - want).max() * FRAC:.0f} units of 2^-36), "
+                          f"ids {int((ids != oids).sum())}", flush=True)
     if (seed - first) % 20 == 19:
         print(f"... {seed - first + 1} seeds done, {bad} mismatches", flush=True)
 print(f"done: {count} seeds, {bad} mismatches")
