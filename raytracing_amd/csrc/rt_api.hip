@@ -408,10 +408,42 @@ static bool spheres_fit_float_screen(const rt_scene_desc* sc, const std::vector<
     return true;
 }
 
+// Splits the objects `rest` (indices into a set) at the median of their centres along the longest axis of the
+// centres' bounding box until at most CLUSTER_SIZE remain; left halves are whole multiples of CLUSTER_SIZE, so all but
+// one cluster are full.  centre(i, k) = k-th coordinate of object i.  Members of a cluster are in ascending order.
+template <class CentreFn>
+static std::vector<std::vector<int>> split_into_clusters(std::vector<int> rest, CentreFn centre) {
+    std::vector<std::vector<int>> clusters;
+    std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}};  // ranges of `rest` still to split
+    while (!todo.empty()) {
+        const auto [lo, hi] = todo.back();
+        todo.pop_back();
+        if (hi - lo <= (size_t)CLUSTER_SIZE) {
+            clusters.emplace_back(rest.begin() + (long)lo, rest.begin() + (long)hi);
+            std::sort(clusters.back().begin(), clusters.back().end());
+            continue;
+        }
+        double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = lo; i < hi; ++i)
+            for (int k = 0; k < 3; ++k) {
+                bmin[k] = std::fmin(bmin[k], centre(rest[i], k));
+                bmax[k] = std::fmax(bmax[k], centre(rest[i], k));
+            }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k)
+            if (bmax[k] - bmin[k] > bmax[axis] - bmin[axis]) axis = k;
+        const size_t half = ((hi - lo) / 2 + CLUSTER_SIZE - 1) / CLUSTER_SIZE * CLUSTER_SIZE;
+        std::nth_element(rest.begin() + (long)lo, rest.begin() + (long)(lo + half), rest.begin() + (long)hi,
+                         [&](int a, int b) { return centre(a, axis) < centre(b, axis); });
+        todo.push_back({lo + half, hi});
+        todo.push_back({lo, lo + half});
+    }
+    return clusters;
+}
+
 // Two-level form of a set (SphereClustersDev) from its screening spheres `sph` (centre, radius >= 0, in set order) and
 // their float images `screen`.  Spheres with more than four times the median radius are "wide"; the others are split
-// at the median of their centres along the longest axis until at most CLUSTER_SIZE remain (left halves are whole
-// multiples of CLUSTER_SIZE, so all but one cluster are full).  A cluster's box encloses its members' screening
+// into clusters by position.  A cluster's box encloses its members' screening
 // spheres and is widened by 2^-20 (B + O), B = largest coordinate of any box, O = cover = eight times that: 8 eps
 // for the float slab test (rt_screen_ops.h) and as much again for the reference's own rounding -- its discriminant,
 // computed in double, can accept a ray that passes a sphere at up to ~3e-8 |o - c| from its surface.
@@ -437,31 +469,8 @@ static int build_sphere_clusters(rt_context* ctx, const std::vector<ScreenSphere
     for (int i = 0; i < n; ++i) (sph[(size_t)i].r > wide_from ? wide : rest).push_back(i);
     if (rest.empty()) return RT_OK;
 
-    std::vector<std::vector<int>> clusters;
-    std::vector<std::pair<size_t, size_t>> todo{{0, rest.size()}};  // ranges of `rest` still to split
-    while (!todo.empty()) {
-        const auto [lo, hi] = todo.back();
-        todo.pop_back();
-        if (hi - lo <= (size_t)CLUSTER_SIZE) {
-            clusters.emplace_back(rest.begin() + (long)lo, rest.begin() + (long)hi);
-            std::sort(clusters.back().begin(), clusters.back().end());
-            continue;
-        }
-        double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (size_t i = lo; i < hi; ++i)
-            for (int k = 0; k < 3; ++k) {
-                bmin[k] = std::fmin(bmin[k], sph[(size_t)rest[i]].c[k]);
-                bmax[k] = std::fmax(bmax[k], sph[(size_t)rest[i]].c[k]);
-            }
-        int axis = 0;
-        for (int k = 1; k < 3; ++k)
-            if (bmax[k] - bmin[k] > bmax[axis] - bmin[axis]) axis = k;
-        const size_t half = ((hi - lo) / 2 + CLUSTER_SIZE - 1) / CLUSTER_SIZE * CLUSTER_SIZE;
-        std::nth_element(rest.begin() + (long)lo, rest.begin() + (long)(lo + half), rest.begin() + (long)hi,
-                         [&](int a, int b) { return sph[(size_t)a].c[axis] < sph[(size_t)b].c[axis]; });
-        todo.push_back({lo + half, hi});
-        todo.push_back({lo, lo + half});
-    }
+    const std::vector<std::vector<int>> clusters =
+        split_into_clusters(rest, [&](int i, int k) { return sph[(size_t)i].c[k]; });
 
     const int n_clusters = (int)clusters.size();
     if (n_clusters > 1024) return RT_OK;  // a queue item of the walk names a cluster in 10 bits
@@ -619,6 +628,61 @@ static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::ve
     B.n = n;
     B.cover = (float)cover;
     if ((double)B.cover > cover) B.cover = std::nextafterf(B.cover, 0.0f);  // never claim more than the margin covers
+
+    // Two-level form: clusters by position of the box centres; a cluster's box is the union of its members' boxes,
+    // widened like theirs (the same bound on the same arithmetic); members keep their own images.
+    if (n < ctx->cluster_min || n >= (int)NO_MEMBER) return RT_OK;
+    std::vector<int> all((size_t)n);
+    for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+    const std::vector<std::vector<int>> clusters = split_into_clusters(all, [&](int i, int k) {
+        const rt_node& nd = sc->nodes[prims[(size_t)i]];
+        return 0.5 * (nd.p[k] + nd.p[3 + k]);
+    });
+    const int n_clusters = (int)clusters.size();
+    if (n_clusters > 1024) return RT_OK;  // a queue item of the walk names a cluster in 10 bits
+    const int cluster_groups = (n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
+    std::vector<BoxPair> cboxes((size_t)cluster_groups * (SCREEN_GROUP / 2));
+    std::memset(cboxes.data(), 0, cboxes.size() * sizeof(BoxPair));
+    BoxPair never;  // a padding slot: negative half-widths, never a candidate
+    for (int k = 0; k < 3; ++k)
+        for (int h = 0; h < 2; ++h) {
+            never.mid[k][h] = 0.0f;
+            never.hw[k][h] = -1.0f;
+        }
+    std::vector<BoxPair> pairs((size_t)n_clusters * (CLUSTER_SIZE / 2), never);
+    std::vector<uint16_t> members((size_t)n_clusters * CLUSTER_SIZE, NO_MEMBER);
+    for (int c = 0; c < n_clusters; ++c) {
+        BoxPair& bp = cboxes[(size_t)c / 2];
+        for (int k = 0; k < 3; ++k) {
+            double lo = INFINITY, hi = -INFINITY;
+            for (int m : clusters[(size_t)c]) {
+                const rt_node& nd = sc->nodes[prims[(size_t)m]];
+                lo = std::fmin(lo, std::fmin(nd.p[k], nd.p[3 + k]));
+                hi = std::fmax(hi, std::fmax(nd.p[k], nd.p[3 + k]));
+            }
+            const double mid = 0.5 * (lo + hi);
+            const float mid_f = (float)mid;
+            const double hw = (0.5 * (hi - lo) + std::fabs(mid - (double)mid_f) + margin) * (1.0 + 1e-12);
+            float hw_f = (float)hw;
+            if ((double)hw_f < hw) hw_f = std::nextafterf(hw_f, INFINITY);
+            bp.mid[k][c & 1] = mid_f;
+            bp.hw[k][c & 1] = hw_f;
+        }
+        for (size_t j = 0; j < clusters[(size_t)c].size(); ++j) {
+            const int m = clusters[(size_t)c][j];
+            BoxPair& dst = pairs[(size_t)c * (CLUSTER_SIZE / 2) + j / 2];
+            const BoxPair& src = screen[(size_t)m / 2];
+            for (int k = 0; k < 3; ++k) {
+                dst.mid[k][j & 1] = src.mid[k][m & 1];
+                dst.hw[k][j & 1] = src.hw[k][m & 1];
+            }
+            members[(size_t)c * CLUSTER_SIZE + j] = (uint16_t)m;
+        }
+    }
+    if ((rc = to_device(ctx, cboxes, &B.clusters.boxes)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, pairs, &B.clusters.pairs)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, members, &B.clusters.members)) != RT_OK) return rc;
+    B.clusters.n_clusters = n_clusters;
     return RT_OK;
 }
 

@@ -78,10 +78,20 @@ struct SphereSetDev {
     const SphereMotion* motion;  // book-2 sphere worlds only, else null
     SphereClustersDev clusters;
 };
+// Two-level form of a large box set, as for spheres: spatial clusters of at most CLUSTER_SIZE boxes, the clusters'
+// bounding boxes for the wave-wide first level, per cluster the images and indices of its members.
+struct BoxClustersDev {
+    int32_t n_clusters;  // 0: the set has no two-level form
+    int32_t pad;
+    const BoxPair* boxes;     // per cluster, padded to whole groups of SCREEN_GROUP
+    const BoxPair* pairs;     // CLUSTER_SIZE / 2 per cluster; a padding slot has a negative half-width: never a candidate
+    const uint16_t* members;  // CLUSTER_SIZE per cluster: index in the set, NO_MEMBER for padding
+};
 struct BoxSetDev {
     int32_t n;
     float cover;            // the margin holds for rays whose origin coordinates are at most this in magnitude
     const BoxPair* screen;  // padded to whole groups of SCREEN_GROUP boxes
+    BoxClustersDev clusters;
 };
 // The leaves of a DEV_NODE_LEAF_SET node: spheres, then boxes.
 struct LeafSetDev {

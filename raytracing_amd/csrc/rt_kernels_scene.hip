@@ -429,24 +429,26 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 if (hit_sphere(d3{sn.p[0], sn.p[1], sn.p[2]}, sn.p[3], loc, loc_a, T_MIN, best.t, t)) {
                                     best.t = t;
                                     best.id = j;
-                                    winner = id;
+                                    best.aux = id;
                                 }
                             });
                             best_t = sh.t;
+                            if (sh.id >= 0) winner = sh.aux;
                             PROBE_MARK(PS_SET_SPHERES);
                         }
                         if constexpr ((F & F_RECT) != 0) {
                             if (set.boxes.n > 0) {
                                 const int first_box = first_slot + set.spheres.n;
-                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, lane, [&](int j, SetHit& best) {
+                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, [&](int j, SetHit& best) {
                                     const SceneNode bn = S.nodes[S.set_nodes[first_box + j]];
                                     const int side = hit_box6(bn.p, loc, T_MIN, best.t);
                                     if (side >= 0) {
                                         best.id = j;
-                                        winner = bn.c + side;
+                                        best.aux = bn.c + side;
                                     }
                                 });
                                 best_t = bh.t;
+                                if (bh.id >= 0) winner = bh.aux;
                                 PROBE_MARK(PS_SET_BOXES);
                             }
                         }

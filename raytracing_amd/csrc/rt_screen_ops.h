@@ -127,15 +127,15 @@ __device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, float cov
 
 typedef __attribute__((address_space(4))) BoxPair ConstBoxPair;
 
-// Screens the two boxes of *p; appends their sign bits (first box first; 1 = no candidate) to mask.
-__device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const ConstBoxPair* p, uint32_t mask) {
+// Screens two boxes given as packed operands (centre and widened half-width per axis); appends their sign bits (first
+// box first; 1 = no candidate) to mask.
+__device__ __forceinline__ uint32_t box_screen_pair_ops(const BoxScreenRay& r, const f2 (&mid)[3], const f2 (&hw)[3], uint32_t mask) {
     f2 near_t[3], far_t[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const f2 hw{p->hw[k][0], p->hw[k][1]};
-        const f2 tc = pk_fma(f2{p->mid[k][0], p->mid[k][1]}, r.inv[k], r.c[k]);
-        near_t[k] = pk_fma(hw, -r.ainv[k], tc);
-        far_t[k] = pk_fma(hw, r.ainv[k], tc);
+        const f2 tc = pk_fma(mid[k], r.inv[k], r.c[k]);
+        near_t[k] = pk_fma(hw[k], -r.ainv[k], tc);
+        far_t[k] = pk_fma(hw[k], r.ainv[k], tc);
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -145,6 +145,18 @@ __device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const
         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(q), 31);
     }
     return mask;
+}
+// The pair *p read through the constant address space (scalar loads, SGPR-pair operands).
+__device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const ConstBoxPair* p, uint32_t mask) {
+    const f2 mid[3] = {f2{p->mid[0][0], p->mid[0][1]}, f2{p->mid[1][0], p->mid[1][1]}, f2{p->mid[2][0], p->mid[2][1]}};
+    const f2 hw[3] = {f2{p->hw[0][0], p->hw[0][1]}, f2{p->hw[1][0], p->hw[1][1]}, f2{p->hw[2][0], p->hw[2][1]}};
+    return box_screen_pair_ops(r, mid, hw, mask);
+}
+// The pair p held in this lane's registers.
+__device__ __forceinline__ uint32_t box_screen_pair(const BoxScreenRay& r, const BoxPair& p, uint32_t mask) {
+    const f2 mid[3] = {f2{p.mid[0][0], p.mid[0][1]}, f2{p.mid[1][0], p.mid[1][1]}, f2{p.mid[2][0], p.mid[2][1]}};
+    const f2 hw[3] = {f2{p.hw[0][0], p.hw[0][1]}, f2{p.hw[1][0], p.hw[1][1]}, f2{p.hw[2][0], p.hw[2][1]}};
+    return box_screen_pair_ops(r, mid, hw, mask);
 }
 
 }  // namespace rtd

@@ -109,21 +109,22 @@ __device__ __forceinline__ f2 splat_from_lane_of(f2 v, int src_lane) {  // src_l
     return f2{f, f};
 }
 
-__device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const ScreenRay& sr, const BoxScreenRay& br, bool on,
-                                                uint16_t* list, uint32_t* rows, int lane, uint32_t& cnt, ProbeClock& pc) {
-    const SphereClustersDev& C = S.clusters;
-    uint16_t* items = (uint16_t*)rows;
-    uint32_t* counts = rows + ITEM_CAP / 2;
+// First level of a two-level walk: the wave tests every lane's ray against the boxes of all clusters (`boxes`, padded
+// to whole groups of SCREEN_GROUP) and queues one item, lane << ITEM_CLUSTER_BITS | cluster, per meeting in `items`
+// (ITEM_CAP slots; positions from the ballot, no atomics).  Returns the number of items; `dropped` is set in lanes that
+// still had clusters to note when the queue was full.
+__device__ __forceinline__ uint32_t queue_cluster_items(const BoxPair* boxes, int n_clusters, const BoxScreenRay& br, bool on,
+                                                        uint16_t* items, int lane, bool& dropped) {
     uint32_t n_items = 0;  // the same in every lane
-    bool dropped = false;
-    const ConstBoxPair* bp = (const ConstBoxPair*)C.boxes;
-    const int n_groups = (C.n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
+    dropped = false;
+    const ConstBoxPair* bp = (const ConstBoxPair*)boxes;
+    const int n_groups = (n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
     for (int g = 0; g < n_groups; ++g) {
         uint32_t mask = 0;
 #pragma unroll
         for (int jj = 0; jj < SCREEN_GROUP / 2; ++jj) mask = box_screen_pair(br, bp + jj, mask);
         bp += SCREEN_GROUP / 2;
-        const int present = C.n_clusters - g * SCREEN_GROUP;  // the image is padded to whole groups
+        const int present = n_clusters - g * SCREEN_GROUP;  // the image is padded to whole groups
         uint32_t cand = on ? ~mask : 0u;
         if (present < SCREEN_GROUP) cand &= ~(0xFFFFFFFFu >> present);
         for (uint64_t busy = ballot(cand != 0u); busy != 0ull; busy = ballot(cand != 0u)) {
@@ -138,6 +139,16 @@ __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const Scr
             if (room) n_items += (uint32_t)__popcll(busy);
         }
     }
+    return n_items;
+}
+
+__device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const ScreenRay& sr, const BoxScreenRay& br, bool on,
+                                                uint16_t* list, uint32_t* rows, int lane, uint32_t& cnt, ProbeClock& pc) {
+    const SphereClustersDev& C = S.clusters;
+    uint16_t* items = (uint16_t*)rows;
+    uint32_t* counts = rows + ITEM_CAP / 2;
+    bool dropped;
+    const uint32_t n_items = queue_cluster_items(C.boxes, C.n_clusters, br, on, items, lane, dropped);
     if (dropped) cnt = (uint32_t)CAND_CAP + 1u;
     if (C.n_wide > 0) screen_all<true>(sr, C.wide_pairs, C.wide_members, C.n_wide, S.n, on, list, lane, cnt);
     counts[lane] = cnt;
@@ -186,6 +197,7 @@ __device__ __forceinline__ void screen_clusters(const SphereSetDev& S, const Scr
 struct SetHit {
     double t;
     int32_t id;
+    int32_t aux = -1;  // whatever the caller's exact test wants to know about the winner (the scene graph: its node)
 };
 
 // sphere::hit up to the accepted root, B1/sphere.h:24-41, inside the closest-so-far loop of
