@@ -850,7 +850,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             if (!spheres_fit_float_screen(sc, spheres)) continue;
             LeafSetDev sd{};
             double lo, hi;
-            int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, false, sd.spheres, lo, hi);
+            int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, true, sd.spheres, lo, hi);
             if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, cover, sd.boxes);
             if (rc != RT_OK) return rc;
             nodes[(size_t)idx].kind = DEV_NODE_LEAF_SET;  // p keeps the subtree's box
