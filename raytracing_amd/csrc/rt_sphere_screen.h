@@ -252,12 +252,14 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     }
 
     const ScreenRay sr = screen_prepare(o, d, a);
-    // A ray with a NaN or an infinity in it (book 3's light sampling produces them: the reference drops such samples at
-    // the end) has no meaningful float screen: the sign of a NaN is arbitrary, so it could name padding entries as
-    // candidates and drop real ones.  The reference's own comparisons all come out false for such a ray, which makes
-    // every object it tests a "hit" -- so the lane tests every member in double, in order, like the reference.
-    const double ray_sum = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
-    const bool finite_ray = ray_sum - ray_sum == 0.0;
+    // The float screen's error bound needs a ray it can hold: origin coordinates of at most 1e15 (like the spheres':
+    // no float product overflows) and a direction of length 1e-100 to 1e100 (no product of the reference's own test
+    // overflows or underflows either).  Any other ray -- a NaN or an infinity (book 3's light sampling produces them: the reference drops such samples at the end), or values
+    // so large that the reference's own products overflow -- has no meaningful screen: a NaN's sign is arbitrary, so it
+    // could name padding entries as candidates and drop real ones.  The reference's comparisons tend to come out false
+    // for such a ray, which makes every object it tests a "hit" -- so the lane tests every member in double, in
+    // order, with the reference's own arithmetic.
+    const bool finite_ray = fabs(o.x) <= 1e15 && fabs(o.y) <= 1e15 && fabs(o.z) <= 1e15 && a >= 1e-200 && a <= 1e200;
     uint32_t cnt = (on && !finite_ray) ? (uint32_t)CAND_CAP + 1u : 0u;
     on = on && finite_ray;  // such lanes take no part in the screen; the overflow pass below serves them
     const uint64_t on_mask = ballot(on);

@@ -104,3 +104,34 @@ def test_wide_spheres_only_world(monkeypatch):
     scene = make_sphere_scene(spheres, MATS, abi.RT_SKY_GRADIENT, (0, 0, 0))
     render_all_ways(monkeypatch, scene, ((14, 3, 9), (0, 0, 0), (0, 1, 0), 50.0, 1.5, 0.1, 12.0),
                     abi.render_params(72, 48, 4, 50, seed=9), (72, 48))
+
+
+def test_rays_with_nan_or_infinity_skip_both_levels(monkeypatch):
+    """A camera origin with a NaN makes every ray one; a lens radius of 1e308 makes directions overflow for part of
+    them.  Such lanes take no part in either level of the screen and test every sphere in double, in order, as the
+    reference's all-false comparisons do; the other lanes of the wave keep the two-level walk."""
+    scene = grid_world(n_side=10)
+    for poison in ("nan origin", "huge lens"):
+        cams = []
+        for mk in (lib.camera, ob.camera):
+            cam = mk((9, 2.5, 7), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.05, 10.0)
+            if poison == "nan origin":
+                cam.origin[1] = float("nan")
+            else:
+                cam.lens_radius = 1.0e308
+            cams.append(cam)
+        cam, ocam = cams
+        p = abi.render_params(24, 16, 2, 50, seed=6)
+        _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, threads=16)
+        for cluster_min in (8, 1 << 20):
+            monkeypatch.setenv("RT_CLUSTER_MIN", str(cluster_min))
+            c = lib.Context(0)
+            try:
+                c.upload(scene)
+                got, st = c.render(cam, p)
+                ids = c.first_hit(cam, 24, 16)
+            finally:
+                c.close()
+            assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (poison, cluster_min)
+            assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (poison, cluster_min)
+            assert np.array_equal(ids, ob.first_hit(scene, ocam, 24, 16)), (poison, cluster_min)
