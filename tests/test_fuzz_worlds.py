@@ -414,14 +414,18 @@ def random_flat_list(seed):
         spheres.append((*c, r, m))
         if mats[m][0] == "dielectric" and rng.random() < 0.3 and len(spheres) < n:
             spheres.append((*c, -0.9 * r, m))  # hollow glass: B1R's trick
-    return make_sphere_scene(spheres[:n], mats, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])), (0.3, 0.4, 0.5)), rng
+    # one world in five at another scale: 1e12 is beyond what the two-level screen's margins cover, 1e17 beyond the float
+    # screen altogether
+    scale = float(rng.choice([1.0] * 8 + [1.0e-6, 1.0e12] if n > 600 else [1.0] * 8 + [1.0e-6, 1.0e5, 1.0e12, 1.0e17]))
+    spheres = [(x * scale, y * scale, z * scale, r * scale, m) for (x, y, z, r, m) in spheres[:n]]
+    return make_sphere_scene(spheres, mats, int(rng.choice([abi.RT_SKY_GRADIENT, abi.RT_SKY_BACKGROUND])), (0.3, 0.4, 0.5)), rng, scale
 
 
 def flat_list_case(seed):
     """World, camera arguments and render parameters of one random book-1 case: odd image sizes, 1 to 130 samples per
     pixel (from 100 on the pixel-by-pixel pass and the accumulation cache), sample offsets, shallow and deep paths,
     cameras that may sit inside a sphere."""
-    scene, rng = random_flat_list(seed)
+    scene, rng, scale = random_flat_list(seed)
     W, H = int(rng.integers(2, 70)), int(rng.integers(2, 50))
     spp = int(rng.choice([1, 3, 8, 17, 104, 130]))
     if spp > 100:
@@ -431,7 +435,8 @@ def flat_list_case(seed):
     lookfrom = tuple(rng.uniform(-9, 9, 3) * (1, 0.2, 1) + (0, 1.5, 0))
     aperture = float(rng.choice([0.0, 0.1, 0.6]))
     vfov = float(rng.choice([20.0, 60.0, 110.0]))
-    cam_args = (lookfrom, (0, 0.5, 0), (0, 1, 0), vfov, W / H, aperture, 6.0)
+    lens = 1.0e300 if rng.random() < 0.04 else aperture * scale  # a lens that makes the rays overflow
+    cam_args = (tuple(x * scale for x in lookfrom), (0, 0.5 * scale, 0), (0, 1, 0), vfov, W / H, lens, 6.0 * scale)
     return scene, cam_args, abi.render_params(W, H, spp, depth, seed=seed * 7919 + 1, sample_begin=begin)
 
 
