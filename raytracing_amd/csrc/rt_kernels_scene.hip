@@ -616,9 +616,17 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
 }
 
 // ---------------------------------------------------------------- textures
+// static_cast<int>(floor(x)) as the reference's x86-64 build computes it: beyond the range of int (and for a NaN) the
+// conversion instruction yields INT_MIN, where the device's own conversion would saturate.  Perlin noise meets such
+// coordinates on very large worlds (its turbulence doubles them six times).
+__device__ __forceinline__ int floor_to_int(double x) {
+    const double f = floor(x);
+    return (f >= -2147483648.0 && f < 2147483648.0) ? (int)f : (int)0x80000000;
+}
+
 __device__ __forceinline__ double perlin_noise(const rt_perlin& pn, d3 p) {  // B2/perlin.h:24-48, 86-104
     const double u = p.x - floor(p.x), v = p.y - floor(p.y), w = p.z - floor(p.z);
-    const int i = (int)floor(p.x), j = (int)floor(p.y), k = (int)floor(p.z);
+    const int i = floor_to_int(p.x), j = floor_to_int(p.y), k = floor_to_int(p.z);
     const double uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
     double accum = 0.0;
 #pragma unroll
@@ -627,7 +635,7 @@ __device__ __forceinline__ double perlin_noise(const rt_perlin& pn, d3 p) {  // 
         for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
-                const int idx = pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255];
+                const int idx = pn.perm_x[((uint32_t)i + (uint32_t)di) & 255u] ^ pn.perm_y[((uint32_t)j + (uint32_t)dj) & 255u] ^ pn.perm_z[((uint32_t)k + (uint32_t)dk) & 255u];
                 const d3 c{pn.ranvec[idx][0], pn.ranvec[idx][1], pn.ranvec[idx][2]};
                 const d3 weight_v{u - di, v - dj, w - dk};
                 accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) *

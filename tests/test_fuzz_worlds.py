@@ -8,6 +8,7 @@ import pytest
 
 from raytracing_amd import abi, lib
 from tests import oracle_binding as ob
+from tests.conftest import gold
 
 pytestmark = pytest.mark.gpu
 FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
@@ -466,3 +467,82 @@ def check_flat_list_case(seed):
 def test_random_flat_list_matches_oracle(seed):
     """The headline kernels on random lists, against the oracle and against their own exact-only mode."""
     check_flat_list_case(6000 + seed)
+
+
+def scale_world(scene, s):
+    """The same world with every length multiplied by s.  Noise textures become grey: their sine takes a world coordinate
+    times a fixed frequency, so on a world 1e4 times larger a last-bit difference of the device libm somewhere up the
+    path (a medium's log) no longer disappears in the accumulation format but comes out as 1e-9 of a colour."""
+    for t in scene.textures:
+        if int(t["kind"]) == abi.RT_TEX_NOISE:
+            t["kind"] = abi.RT_TEX_SOLID
+            t["p"][:3] = 0.5
+    lengths = {abi.RT_NODE_SPHERE: [0, 1, 2, 3], abi.RT_NODE_MOVING_SPHERE: [0, 1, 2, 3, 4, 5, 8],
+               abi.RT_NODE_XY_RECT: [0, 1, 2, 3, 4], abi.RT_NODE_XZ_RECT: [0, 1, 2, 3, 4], abi.RT_NODE_YZ_RECT: [0, 1, 2, 3, 4],
+               abi.RT_NODE_BOX: [0, 1, 2, 3, 4, 5], abi.RT_NODE_BVH: [0, 1, 2, 3, 4, 5], abi.RT_NODE_TRANSLATE: [0, 1, 2],
+               abi.RT_NODE_ROTATE_Y: [3, 4, 5, 6, 7, 8], abi.RT_NODE_MEDIUM: [0]}
+    for n in scene.nodes:
+        for k in lengths.get(int(n["kind"]), []):
+            n["p"][k] *= s
+    return scene
+
+
+@pytest.mark.parametrize("seed,scale", [(s, sc) for s in range(6) for sc in (1.0e-4, 1.0e4, 1.0e7)])
+def test_random_world_at_other_scales(seed, scale, monkeypatch):
+    """Random scene graphs shrunk and blown up: the margins of the leaf sets' screens follow the world's extent, and
+    beyond 8e6 the box sets give way to the tree walk."""
+    scene = scale_world(random_world(1000 + seed), scale)
+    mk = lambda f: f((7 * scale, 3.5 * scale, 8 * scale), (0, 0.7 * scale, 0), (0, 1, 0), 32.0, 4.0 / 3.0, 0.05 * scale, 10.0 * scale, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(48, 36, 3, 50, seed=seed)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    for set_min in (2, 1000):
+        monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+        monkeypatch.setenv("RT_CLUSTER_MIN", "4")
+        c = lib.Context(0)
+        try:
+            c.upload(scene)
+            got, st = c.render(cam, p)
+            ids = c.first_hit(cam, 60, 45)
+        finally:
+            c.close()
+        assert st["rays"] == ost["rays"], (seed, scale, set_min)
+        assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, scale, set_min)
+        assert np.array_equal(ids, ob.first_hit(scene, ocam, 60, 45)), (seed, scale, set_min)
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0e7, 1.0e10])
+def test_perlin_noise_beyond_the_int_range(scale):
+    """Perlin noise converts floor(coordinate) to int; on a world of 1e8 and more that leaves the range of int, where the
+    reference's x86-64 build gets INT_MIN from the conversion (the turbulence doubles the coordinate six times, so
+    3e7 overflows in its last octaves only).  Spheres only: nothing up the path calls the libm."""
+    tex = np.zeros(2, abi.TEXTURE_DTYPE)
+    tex["kind"] = abi.RT_TEX_NOISE
+    tex["a"] = 0
+    tex["p"][0][0], tex["p"][1][0] = 4.0, 0.3
+    mat = np.zeros(2, abi.MATERIAL_DTYPE)
+    mat["kind"] = abi.RT_MAT_LAMBERTIAN
+    mat["texture"] = [0, 1]
+    nodes = np.zeros(4, abi.NODE_DTYPE)
+    for i, (c, r, m) in enumerate([((0, -1000, 0), 1000, 0), ((0, 2, 0), 2, 1), ((4, 1, 1), 1, 0)]):
+        nodes[i]["kind"], nodes[i]["material"] = abi.RT_NODE_SPHERE, m
+        nodes[i]["p"][:4] = (*c, r)
+    nodes[3]["kind"], nodes[3]["child0"], nodes[3]["child1"], nodes[3]["material"] = abi.RT_NODE_LIST, 0, 3, -1
+    base = abi.load_scene(gold("scene_b2_two_perlin.rtsc"))
+    scene = abi.Scene(root=3, nodes=nodes, children=np.arange(3, dtype=np.int32), materials=mat, textures=tex,
+                      perlins=base.perlins[:1].copy(), sky_mode=abi.RT_SKY_GRADIENT)
+    for n in scene.nodes[:3]:
+        n["p"][:4] *= scale
+    mk = lambda f: f((13 * scale, 2 * scale, 3 * scale), (0, 0, 0), (0, 1, 0), 30.0, 1.5, 0.0, 10.0 * scale, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(60, 40, 4, 50, seed=3)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    c = lib.Context(0)
+    try:
+        c.upload(scene)
+        c.set_force_graph(True)
+        got, st = c.render(cam, p)
+    finally:
+        c.close()
+    assert st["rays"] == ost["rays"]
+    assert np.array_equal(got, fixed.astype(np.float64) / FRAC)
