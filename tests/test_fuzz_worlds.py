@@ -487,11 +487,13 @@ def scale_world(scene, s):
     return scene
 
 
-@pytest.mark.parametrize("seed,scale", [(s, sc) for s in range(6) for sc in (1.0e-4, 1.0e4, 1.0e7)])
-def test_random_world_at_other_scales(seed, scale, monkeypatch):
-    """Random scene graphs shrunk and blown up: the margins of the leaf sets' screens follow the world's extent, and
-    beyond 8e6 the box sets give way to the tree walk."""
-    scene = scale_world(random_world(1000 + seed), scale)
+@pytest.mark.parametrize("family,seed,scale", [("graph", s, sc) for s in range(6) for sc in (1.0e-4, 1.0e4, 1.0e7)] +
+                         [(f, s, sc) for f in ("spheres", "big sets") for s in range(3) for sc in (1.0e-4, 1.0e4, 1.0e7)])
+def test_random_world_at_other_scales(family, seed, scale, monkeypatch):
+    """Random worlds shrunk and blown up: the margins of the screens follow the world's extent; beyond 8e6 the box sets
+    give way to the tree walk, beyond 1e6 the two-level screens to the one-level ones."""
+    make = {"graph": random_world, "spheres": random_sphere_world, "big sets": random_big_set_world}[family]
+    scene = scale_world(make(1000 + seed), scale)
     mk = lambda f: f((7 * scale, 3.5 * scale, 8 * scale), (0, 0.7 * scale, 0), (0, 1, 0), 32.0, 4.0 / 3.0, 0.05 * scale, 10.0 * scale, 0.0, 1.0)
     cam, ocam = mk(lib.camera), mk(ob.camera)
     p = abi.render_params(48, 36, 3, 50, seed=seed)

@@ -24,8 +24,11 @@ for seed in range(first, first + count):
         if name == "big sets" and seed % 4 != 0:  # the large worlds cost the oracle more: one seed in four
             continue
         scene = gen(seed)
+        sc = (1.0, 1.0, 1.0, 1.0e-4, 1.0e4, 1.0e7)[(seed // 2) % 6]  # half of the worlds at another scale (noise greyed)
+        if sc != 1.0:
+            scene = t.scale_world(scene, sc)
         t0, t1 = ((0.0, 1.0), (0.25, 0.5), (0.0, 0.0), (-0.5, 1.5))[seed % 4] if name == "spheres" else (0.0, 1.0)
-        mk = lambda f: f((7 + seed % 3, 3.5, 8 - seed % 2), (0, 0.7, 0), (0, 1, 0), 32.0 + seed % 7, 4.0 / 3.0, 0.05 * (seed % 2), 10.0, t0, t1)
+        mk = lambda f: f(((7 + seed % 3) * sc, 3.5 * sc, (8 - seed % 2) * sc), (0, 0.7 * sc, 0), (0, 1, 0), 32.0 + seed % 7, 4.0 / 3.0, 0.05 * (seed % 2) * sc, 10.0 * sc, t0, t1)
         cam, ocam = mk(lib.camera), mk(ob.camera)
         for flags in flags_list:
             p = abi.render_params(48, 36, 3, 50, seed=seed, flags=flags)
@@ -43,7 +46,7 @@ for seed in range(first, first + count):
                     c.close()
                 if st["rays"] != ost["rays"] or not np.array_equal(got, want) or not np.array_equal(ids, oids):
                     bad += 1
-                    print(f"MISMATCH seed {seed} {name} flags {flags} set_min {set_min}: rays {st['rays']} vs {ost['rays']}, "
+                    print(f"MISMATCH seed {seed} {name} scale {sc:g} flags {flags} set_min {set_min}: rays {st['rays']} vs {ost['rays']}, "
                           f"pixels {int(np.any(got != want, axis=2).sum())} (largest difference {np.abs(got - want).max() * FRAC:.0f} units of 2^-36), "
                           f"ids {int((ids != oids).sum())}", flush=True)
     if (seed - first) % 20 == 19:
