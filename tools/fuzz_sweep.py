@@ -28,7 +28,11 @@ for seed in range(first, first + count):
         if sc != 1.0:
             scene = t.scale_world(scene, sc)
         t0, t1 = ((0.0, 1.0), (0.25, 0.5), (0.0, 0.0), (-0.5, 1.5))[seed % 4] if name == "spheres" else (0.0, 1.0)
-        mk = lambda f: f(((7 + seed % 3) * sc, 3.5 * sc, (8 - seed % 2) * sc), (0, 0.7 * sc, 0), (0, 1, 0), 32.0 + seed % 7, 4.0 / 3.0, 0.05 * (seed % 2) * sc, 10.0 * sc, t0, t1)
+        # now and then a lens that makes the rays overflow -- not for worlds with an image texture: a NaN texture
+        # coordinate indexes the image out of bounds in the reference (and in the oracle, which then crashes)
+        huge_lens = seed % 11 == 3 and not np.any(scene.textures["kind"] == abi.RT_TEX_IMAGE)
+        mk = lambda f: f(((7 + seed % 3) * sc, 3.5 * sc, (8 - seed % 2) * sc), (0, 0.7 * sc, 0), (0, 1, 0), 32.0 + seed % 7, 4.0 / 3.0,
+                        1.0e300 if huge_lens else 0.05 * (seed % 2) * sc, 10.0 * sc, t0, t1)
         cam, ocam = mk(lib.camera), mk(ob.camera)
         for flags in flags_list:
             p = abi.render_params(48, 36, 3, 50, seed=seed, flags=flags)
