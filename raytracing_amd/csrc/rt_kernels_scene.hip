@@ -759,9 +759,9 @@ __device__ __forceinline__ d3 shape_random(const SceneNode& n, d3 origin, uint32
 }
 // One lambertian bounce of the book's ray_color: direction from the 50/50 mixture of the light density and the
 // cosine density; returns  (1 / pdf_val) * (scattering_pdf * attenuation)  as the factor of the throughput.
-__device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 normal, d3 attenuation, const RngCtx& g, d3& dir) {
+// ph = Philox block 0 of the site.
+__device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 normal, d3 attenuation, const RngCtx& g, u32x4 ph, d3& dir) {
     const Onb uvw = onb_from_w(normal);
-    const u32x4 ph = philox4x32_10(g.pixel, g.sample, g.site, 0u, g.k0, g.k1);
     if (u01(ph.x) < 0.5) {
         const int idx = (int)u_range(ph.y, 0, (S.n_lights - 1) + 1);
         dir = shape_random(S.nodes[S.lights[idx < MAX_LIGHT_SHAPES ? idx : 0]], p, ph.z, ph.w);
@@ -879,14 +879,16 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 const bool importance = (F & F_IS) != 0;  // variants with F_IS only run with RT_RENDER_IMPORTANCE
                 const bool wants_sphere = (!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
                                           (!importance && m.kind == RT_MAT_ISOTROPIC);
-                const d3 rs = random_in_unit_sphere(wants_sphere, g.pixel, g.sample, g.site, A.key0, A.key1);
+                // Philox block 0 of the site is every material's first draw (sphere sampler, reflectance, light mixture)
+                const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
+                const d3 rs = random_in_unit_sphere(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1);
                 // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code)
                 const bool wants_texture = m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
                                            (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face));
                 d3 tex{0, 0, 0};
                 if (wants_texture) tex = texture_value<F>(S, m.tex, s);
                 if (importance && m.kind == RT_MAT_LAMBERTIAN) {  // book 3: mixture of light and cosine densities
-                    attenuation = importance_bounce(S, s.p, s.normal, tex, g, nd);
+                    attenuation = importance_bounce(S, s.p, s.normal, tex, g, block0, nd);
                 } else if (importance && m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
                     // book 3: a light emits from its front face only and ends the path; nothing else scatters
                     if (m.kind == RT_MAT_DIFFUSE_LIGHT && s.front_face) L_end = tex;
@@ -908,10 +910,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                     const double cos_theta = fmin(dot(-unit_direction, s.normal), 1.0);
                     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
-                    if (!do_reflect) {
-                        const u32x4 w = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
-                        do_reflect = reflectance(cos_theta, refraction_ratio) > u01(w.x);
-                    }
+                    if (!do_reflect) do_reflect = reflectance(cos_theta, refraction_ratio) > u01(block0.x);
                     nd = do_reflect ? reflect(unit_direction, s.normal) : refract(unit_direction, s.normal, refraction_ratio);
                 } else if ((F & F_MEDIUM) != 0 && m.kind == RT_MAT_ISOTROPIC) {  // B2/material.h:121-127
                     nd = rs;

@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                 }
                 d3 nd{0, 0, 0};
                 const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL;
-                const d3 rs = random_in_unit_sphere(wants_sphere, pixel, sample, site, A.key0, A.key1);
+                const u32x4 block0 = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);  // every material's first draw
+                const d3 rs = random_in_unit_sphere(wants_sphere, block0, pixel, sample, site, A.key0, A.key1);
                 if (m.kind == RT_MAT_LAMBERTIAN) {  // B1/material.h:19-30
                     nd = normal + unit_vector(rs);
                     const double s = 1e-8;
@@ -189,10 +190,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
                     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
-                    if (!do_reflect) {
-                        const u32x4 ph = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);
-                        do_reflect = reflectance(cos_theta, refraction_ratio) > u01(ph.x);
-                    }
+                    if (!do_reflect) do_reflect = reflectance(cos_theta, refraction_ratio) > u01(block0.x);
                     nd = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
                 }
                 if (!done) {

@@ -36,8 +36,10 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int
     d = llc + s * hor + t * ver - origin - offset;
 }
 
-// random_in_unit_sphere, B1/vec3.h:114-120, for the lanes with need == true.
-__device__ __forceinline__ d3 random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t site,
+// random_in_unit_sphere, B1/vec3.h:114-120, for the lanes with need == true.  block0 = Philox block 0 of the site,
+// computed by the caller (the dielectric's reflectance draw of the same site reads the same block: one evaluation
+// serves the lanes of either kind).
+__device__ __forceinline__ d3 random_in_unit_sphere(bool need, u32x4 block0, uint32_t pixel, uint32_t sample, uint32_t site,
                                                     uint32_t k0, uint32_t k1) {
     d3 p{0, 0, 0};
     uint32_t sx = 0, sy = 0, sz = 0;  // words 3 of the last three blocks: the fourth attempt of each group
@@ -48,7 +50,7 @@ __device__ __forceinline__ d3 random_in_unit_sphere(bool need, uint32_t pixel, u
             y = sy;
             z = sz;
         } else {
-            const u32x4 w = philox4x32_10(pixel, sample, site, 3u * (k >> 2) + (k & 3u), k0, k1);
+            const u32x4 w = k == 0u ? block0 : philox4x32_10(pixel, sample, site, 3u * (k >> 2) + (k & 3u), k0, k1);
             x = w.x;
             y = w.y;
             z = w.z;
