@@ -35,6 +35,14 @@ struct u32x4 {
 
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RT_PHILOX_OPAQUE_KEY)
+    // (sphere-list kernels only: the scene-graph kernels, bound by latency rather than issue slots, lose 1-3 % to it)
+    // The key is the same for the whole launch, so the compiler would work out the twenty round keys once and hold them
+    // in scalar registers across the render loop -- more than there are: they end up spilled to vector lanes and read
+    // back one by one in every round.  Made opaque here, the keys of a block are derived where they are used, by
+    // scalar additions that cost no vector issue slot.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;

@@ -29,6 +29,7 @@
 //
 // The float screen can only add candidates, never drop a true hit (bound in screen_prepare),
 // so the rendered numbers are those of an all-double renderer.
+#define RT_PHILOX_OPAQUE_KEY 1  // see philox4x32_10
 #include "rt_device_common.h"
 #include "rt_internal.h"
 #include "rt_render_common.h"
