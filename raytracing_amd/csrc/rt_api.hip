@@ -588,8 +588,6 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
     if ((rc = to_device(ctx, exact, &S.exact)) != RT_OK) return rc;
     if (timed && (rc = to_device(ctx, motion, &S.motion)) != RT_OK) return rc;
     S.n = n;
-    S.n_full_groups = n / SCREEN_GROUP;
-    S.n_tail_pairs = (n % SCREEN_GROUP + 1) / 2;
     S.n_chunks = n_chunks;
     if (two_level) return build_sphere_clusters(ctx, sph, screen, S.clusters);
     return RT_OK;

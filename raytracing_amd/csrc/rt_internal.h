@@ -70,8 +70,6 @@ struct SphereClustersDev {
 
 struct SphereSetDev {
     int32_t n;         // spheres in list order (= object ids)
-    int32_t n_full_groups;  // n / SCREEN_GROUP: groups screened by the unrolled loop
-    int32_t n_tail_pairs;   // pairs of the last, partial group (0..15); an odd sphere is padded
     int32_t n_chunks;       // 256-pair chunks of the screen image (padded with never-hit pairs to a whole chunk)
     const SpherePair* screen;
     const SphereExact* exact;
