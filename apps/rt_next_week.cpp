@@ -2,7 +2,7 @@
 // its switch does, build it with the reference's own calls, render on the GPU through the C ABI, write P3.
 //
 //   rt_next_week [--scene N|name] [--width W] [--spp N] [--depth D] [--seed S] [--earth file.ppm]
-//                [--dump-scene file.rtsc] [--no-render]  > image.ppm
+//                [--gpus N] [--mode render|firsthit] [--dump-scene file.rtsc] [--no-render]  > image.ppm
 //
 // Scenes: 1 bouncing, 2 two_spheres, 3 two_perlin, 4 earth, 5 simple_light, 6 cornell_box, 7 cornell_smoke,
 // 8 final (the reference's default).  Width / spp default to the reference's literals for that scene.
@@ -17,23 +17,21 @@
 
 #include "raytracing_amd.h"
 #include "rt_scene_io.h"
+#include "app_common.hpp"
 #include "../raytracing_amd/host/scenes_b2.hpp"
 
 using namespace rtw;
-
-static int die(rt_context* ctx, int rc, const char* what) {
-    std::fprintf(stderr, "%s: %s (%s)\n", what, rt_error_string(rc), rt_last_error_detail(ctx));
-    return 1;
-}
 
 int main(int argc, char** argv) {
     std::string which = "8", dump, earth_path = "earthmap.ppm";
     int width_arg = 0, spp_arg = 0, max_depth = 50;
     unsigned long long seed = 1;
+    app::options common;
     bool render = true;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
+        if (app::parse_common(common, argc, argv, i)) continue;
         if (a == "--scene") which = next();
         else if (a == "--width") width_arg = std::atoi(next());
         else if (a == "--spp") spp_arg = std::atoi(next());
@@ -85,26 +83,13 @@ int main(int argc, char** argv) {
     }
     if (!render) return 0;
 
-    rt_context* ctx = nullptr;
-    int rc = rt_context_create(0, nullptr, &ctx);
-    if (rc != RT_OK) return die(nullptr, rc, "rt_context_create");
-    if ((rc = rt_scene_upload(ctx, &scene)) != RT_OK) return die(ctx, rc, "rt_scene_upload");
     rt_render_params p;
     std::memset(&p, 0, sizeof(p));
     p.width = image_width;
     p.height = image_height;
+    p.sample_begin = 0;
     p.sample_count = samples_per_pixel;
     p.max_depth = max_depth;
     p.seed = seed;
-    std::vector<double> sums((size_t)3 * image_width * image_height);
-    rt_stats st;
-    if ((rc = rt_render(ctx, &cam.desc(), &p, sums.data(), &st)) != RT_OK) return die(ctx, rc, "rt_render");
-    std::fprintf(stderr, "scene %d, %dx%d, %d spp: kernel %.1f ms (%.1f Msamples/s, %.2f rays/sample)\n", scene_no, image_width,
-                 image_height, samples_per_pixel, st.kernel_ms, st.samples / st.kernel_ms / 1e3, (double)st.rays / (double)st.samples);
-    std::vector<uint8_t> rgb(sums.size());
-    rt_write_color(sums.data(), image_width, image_height, samples_per_pixel, rgb.data());
-    if ((rc = rt_write_ppm("/dev/stdout", rgb.data(), image_width, image_height)) != RT_OK) return die(ctx, rc, "rt_write_ppm");
-    std::fprintf(stderr, "\nDone.\n");
-    rt_context_destroy(ctx);
-    return 0;
+    return app::run(common, scene, cam.desc(), p, names[scene_no >= 1 && scene_no <= 8 ? scene_no : 8]);
 }

@@ -3,7 +3,7 @@
 // write the P3 image to stdout.
 //
 //   rt_one_weekend [--scene final|three] [--width W] [--spp N] [--depth D] [--seed S]
-//                  [--dump-scene file.rtsc] [--no-render]  > image.ppm
+//                  [--gpus N] [--mode render|firsthit] [--dump-scene file.rtsc] [--no-render]  > image.ppm
 //
 // Defaults are the reference's literals: 1200x800, 500 spp, depth 50, final scene.
 #include <chrono>
@@ -15,23 +15,21 @@
 
 #include "raytracing_amd.h"
 #include "rt_scene_io.h"
+#include "app_common.hpp"
 #include "../raytracing_amd/host/scenes_b1.hpp"
 
 using namespace rtw;
-
-static int die(rt_context* ctx, int rc, const char* what) {
-    std::fprintf(stderr, "%s: %s (%s)\n", what, rt_error_string(rc), rt_last_error_detail(ctx));
-    return 1;
-}
 
 int main(int argc, char** argv) {
     std::string which = "final", dump;
     int image_width = 1200, samples_per_pixel = 500, max_depth = 50;
     unsigned long long seed = 1;
+    app::options common;
     bool render = true;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
+        if (app::parse_common(common, argc, argv, i)) continue;
         if (a == "--scene") which = next();
         else if (a == "--width") image_width = std::atoi(next());
         else if (a == "--spp") samples_per_pixel = std::atoi(next());
@@ -76,11 +74,6 @@ int main(int argc, char** argv) {
     }
     if (!render) return 0;
 
-    rt_context* ctx = nullptr;
-    int rc = rt_context_create(0, nullptr, &ctx);
-    if (rc != RT_OK) return die(nullptr, rc, "rt_context_create");
-    if ((rc = rt_scene_upload(ctx, &scene)) != RT_OK) return die(ctx, rc, "rt_scene_upload");
-
     rt_render_params p;
     std::memset(&p, 0, sizeof(p));
     p.width = image_width;
@@ -89,19 +82,5 @@ int main(int argc, char** argv) {
     p.sample_count = samples_per_pixel;
     p.max_depth = max_depth;
     p.seed = seed;
-    std::vector<double> sums((size_t)3 * image_width * image_height);
-    rt_stats st;
-    const auto t0 = std::chrono::steady_clock::now();
-    if ((rc = rt_render(ctx, &cam.desc(), &p, sums.data(), &st)) != RT_OK) return die(ctx, rc, "rt_render");
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "%dx%d, %d spp: kernel %.1f ms (%.1f Msamples/s, %.2f rays/sample), call %.1f ms\n", image_width,
-                 image_height, samples_per_pixel, st.kernel_ms, st.samples / st.kernel_ms / 1e3,
-                 (double)st.rays / (double)st.samples, wall * 1e3);
-
-    std::vector<uint8_t> rgb(sums.size());
-    rt_write_color(sums.data(), image_width, image_height, samples_per_pixel, rgb.data());
-    if ((rc = rt_write_ppm("/dev/stdout", rgb.data(), image_width, image_height)) != RT_OK) return die(ctx, rc, "rt_write_ppm");
-    std::fprintf(stderr, "\nDone.\n");
-    rt_context_destroy(ctx);
-    return 0;
+    return app::run(common, scene, cam.desc(), p, which.c_str());
 }

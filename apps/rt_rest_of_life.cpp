@@ -2,7 +2,8 @@
 // repository holds no book-3 code): Cornell box with a glass sphere, light sampled by importance, rendered on the
 // GPU through the C ABI with RT_RENDER_IMPORTANCE, written as P3.
 //
-//   rt_rest_of_life [--width W] [--spp N] [--depth D] [--seed S] [--plain] [--dump-scene file.rtsc] [--no-render]
+//   rt_rest_of_life [--width W] [--spp N] [--depth D] [--seed S] [--plain] [--gpus N] [--mode render|firsthit]
+//                   [--dump-scene file.rtsc] [--no-render]
 //
 // --plain renders the same world without importance sampling (book-2 ray_color): both converge to the same image
 // up to the one-sided light, which is what the tests use in place of a reference image.
@@ -14,23 +15,21 @@
 
 #include "raytracing_amd.h"
 #include "rt_scene_io.h"
+#include "app_common.hpp"
 #include "../raytracing_amd/host/scenes_b3.hpp"
 
 using namespace rtw;
 
-static int die(rt_context* ctx, int rc, const char* what) {
-    std::fprintf(stderr, "%s: %s (%s)\n", what, rt_error_string(rc), rt_last_error_detail(ctx));
-    return 1;
-}
-
 int main(int argc, char** argv) {
     int image_width = 600, samples_per_pixel = 1000, max_depth = 50;
     unsigned long long seed = 1;
+    app::options common;
     bool render = true, plain = false;
     std::string dump;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
+        if (app::parse_common(common, argc, argv, i)) continue;
         if (a == "--width") image_width = std::atoi(next());
         else if (a == "--spp") samples_per_pixel = std::atoi(next());
         else if (a == "--depth") max_depth = std::atoi(next());
@@ -56,28 +55,14 @@ int main(int argc, char** argv) {
     }
     if (!render) return 0;
 
-    rt_context* ctx = nullptr;
-    int rc = rt_context_create(0, nullptr, &ctx);
-    if (rc != RT_OK) return die(nullptr, rc, "rt_context_create");
-    if ((rc = rt_scene_upload(ctx, &scene)) != RT_OK) return die(ctx, rc, "rt_scene_upload");
     rt_render_params p;
     std::memset(&p, 0, sizeof(p));
     p.width = image_width;
     p.height = image_height;
+    p.sample_begin = 0;
     p.sample_count = samples_per_pixel;
     p.max_depth = max_depth;
     p.seed = seed;
     p.flags = plain ? 0 : RT_RENDER_IMPORTANCE;
-    std::vector<double> sums((size_t)3 * image_width * image_height);
-    rt_stats st;
-    if ((rc = rt_render(ctx, &cam.desc(), &p, sums.data(), &st)) != RT_OK) return die(ctx, rc, "rt_render");
-    std::fprintf(stderr, "%dx%d, %d spp: kernel %.1f ms (%.1f Msamples/s, %.2f rays/sample, %llu non-finite samples dropped)\n",
-                 image_width, image_height, samples_per_pixel, st.kernel_ms, st.samples / st.kernel_ms / 1e3,
-                 (double)st.rays / (double)st.samples, (unsigned long long)st.nan_samples);
-    std::vector<uint8_t> rgb(sums.size());
-    rt_write_color(sums.data(), image_width, image_height, samples_per_pixel, rgb.data());
-    if ((rc = rt_write_ppm("/dev/stdout", rgb.data(), image_width, image_height)) != RT_OK) return die(ctx, rc, "rt_write_ppm");
-    std::fprintf(stderr, "\nDone.\n");
-    rt_context_destroy(ctx);
-    return 0;
+    return app::run(common, scene, cam.desc(), p, plain ? "cornell box, plain" : "cornell box, light sampled by importance");
 }

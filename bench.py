@@ -3,15 +3,25 @@
 
 A step is one full frame of the reference's render loop over the dumped 487-sphere world:
 1200x800 pixels, 500 samples per pixel, depth 50, camera of RayTracing.cpp:104-110.  With N
-ranks (one process per GPU, launched by torch.distributed.run) the 500 samples of every pixel
-are split 63/62 over the ranks and the fixed-point accumulation buffers are summed by one RCCL
-all-reduce per frame, so the N-GPU frame equals the 1-GPU frame bit for bit ("strong" scaling:
-total work is fixed).  Scene and accumulation buffer are resident in HBM before the timed
-region; tone mapping and PPM output are outside it.
+GPUs the 500 samples of every pixel are split 63/62 over the GPUs and the fixed-point
+accumulation buffers are summed by one RCCL all-reduce per frame inside the library
+(rt_group_*), so the N-GPU frame equals the 1-GPU frame bit for bit ("strong" scaling: total
+work is fixed).  Scene and accumulation buffers are resident in HBM before the timed region;
+tone mapping and PPM output are outside it.
 
-Prints ONE JSON line on rank 0.
+Three ways to start it:
+  python3 bench.py                         one GPU, one rt_context
+  python -m torch.distributed.run ... bench.py --gpus N    one process per GPU: rank 0 makes the RCCL id, hands it
+                                           round over torch.distributed (gloo, control plane only: id, barriers, the
+                                           MAX of the ranks' times), every rank joins with rt_group_create_rank
+  python3 bench.py --gpus N                one process driving N GPUs (rt_group_create = ncclCommInitAll)
+
+Prints ONE JSON line on rank 0.  With several GPUs `value` is the throughput of frames kept in flight
+(--frames-in-flight, default 3: the tail of one frame and its all-reduce overlap the next frame); the time of a
+frame rendered alone, first launch to summed buffer complete, is reported beside it as `single_frame`.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -36,6 +46,17 @@ def algorithmic_flop(n_objects, rays, samples):
     return rays * (n_objects * 23.0 + 60.0) + samples * 40.0
 
 
+def kernel_source_sha256():
+    """Hash of the kernel sources the library is built from: a committed counter summary carries the hash of the tree
+    it was measured on, so figures taken from it can be marked stale once the kernels have changed."""
+    import glob
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.h*"))):
+        with open(path, "rb") as fp:
+            h.update(os.path.basename(path).encode() + b"\0" + fp.read())
+    return h.hexdigest()
+
+
 def profiled_execution(n_objects):
     """What k_render_spheres executes per ray, from the newest committed rocprofv3 counter summary of this command
     (profiles/*_bench_c2.json, tools/profile_bench.sh): vector flops as the hardware counts them
@@ -57,7 +78,7 @@ def profiled_execution(n_objects):
             flop = 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP32"] + c["SQ_INSTS_VALU_FLOPS_FP64"] + c["SQ_INSTS_VALU_FLOPS_FP64_TRANS"])
             best = {"flop_per_ray": flop / rays, "fp64_share": 64.0 * (c["SQ_INSTS_VALU_FLOPS_FP64"] + c["SQ_INSTS_VALU_FLOPS_FP64_TRANS"]) / flop,
                     "valu_issue_utilisation": d["valu_busy_estimate"], "lanes_active": d["valu_lane_utilisation"],
-                    "source": os.path.relpath(path, ROOT)}
+                    "source": os.path.relpath(path, ROOT), "kernel_source_sha256": prof.get("kernel_source_sha256")}
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return best
@@ -132,6 +153,81 @@ def cpu_baseline_all_cores(processes):
             "sample": f"{processes} processes of the unmodified reference, distinct srand() seeds, {W}x{H}x{spp} each, run together"}
 
 
+class OneGpu:
+    """N = 1: rt_context + rt_render_device into a torch buffer, one frame in flight per slot."""
+
+    def __init__(self, torch, lib, abi, scene, cam, W, H, spp, depth, n_slots):
+        self.torch, self.abi, self.cam, self.dims = torch, abi, cam, (W, H, spp, depth)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        self.dev, self.slots = dev, []
+        for _ in range(n_slots):
+            s = torch.cuda.Stream(device=dev)
+            c = lib.Context(0, s.cuda_stream)
+            c.upload(scene)
+            with torch.cuda.stream(s):
+                buf = torch.zeros((H, W, 3), dtype=torch.int64, device=dev)
+            self.slots.append((s, c, buf))
+
+    def submit(self, k):
+        W, H, spp, depth = self.dims
+        s, c, buf = self.slots[k % len(self.slots)]
+        with self.torch.cuda.stream(s):
+            buf.zero_()
+            c.render_device(self.cam, self.abi.render_params(W, H, spp, depth, seed=1 + k), buf.data_ptr())
+
+    def wait_frame(self, k):
+        self.slots[k % len(self.slots)][0].synchronize()
+
+    def drain(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def take_stats(self):
+        st = {"samples": 0, "rays": 0, "nan_samples": 0, "kernel_ms": 0.0, "kernel_launches": 0}
+        for _, c, _ in self.slots:
+            one = c.take_stats()
+            for key in st:
+                st[key] += one[key]
+        return st
+
+    def close(self):
+        for _, c, _ in self.slots:
+            c.close()
+
+
+class ManyGpus:
+    """N > 1: an rt_group (this process's members of it); frames go round its slots."""
+
+    def __init__(self, group, abi, scene, cam, W, H, spp, depth):
+        self.g, self.abi, self.cam, self.dims = group, abi, cam, (W, H, spp, depth)
+        self.g.upload(scene)
+        self.busy = [False] * group.frame_slots
+
+    def submit(self, k):
+        W, H, spp, depth = self.dims
+        slot = k % len(self.busy)
+        if self.busy[slot]:          # a slot is waited for before it takes another frame
+            self.g.wait(slot)
+        self.g.render_async(self.cam, self.abi.render_params(W, H, spp, depth, seed=1 + k), slot)
+        self.busy[slot] = True
+
+    def wait_frame(self, k):
+        slot = k % len(self.busy)
+        self.g.wait(slot)
+        self.busy[slot] = False
+
+    def drain(self):
+        for slot in range(len(self.busy)):
+            self.g.wait(slot)
+            self.busy[slot] = False
+
+    def take_stats(self):
+        return self.g.take_stats()
+
+    def close(self):
+        self.g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,160 +238,155 @@ def main():
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently on separate HIP streams (each with its own accumulation "
-                         "buffer), so that the long-path tail of one frame and its all-reduce overlap the next "
-                         "frame.  Default: 1 on one GPU (kernel timings stay per launch), 3 with several ranks (with 2, "
-                         "frame k+2 would queue behind the all-reduce of frame k on the same stream, and that collective "
-                         "only finds free CUs once frame k+1 nears its end)")
+                    help="frames rendered concurrently, each on its own HIP stream and accumulation buffer, so that "
+                         "the long-path tail of one frame and its all-reduce overlap the next frame.  Default: 1 on "
+                         "one GPU (kernel timings stay per launch), 3 on several (with 2, frame k+2 would queue "
+                         "behind the all-reduce of frame k on the same stream, and that collective only finds free "
+                         "CUs once frame k+1 nears its end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from raytracing_amd import abi, frame, lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    # Rehearsal on a one-GPU box: RT_BENCH_SHARE_GPU=1 puts every rank on device 0 and RT_BENCH_BACKEND=gloo
-    # replaces RCCL (which refuses two ranks on one device); the normal path is one GPU per rank over nccl.
-    if os.environ.get("RT_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    force_reduce = os.environ.get("RT_BENCH_FORCE_REDUCE") == "1"   # rehearsal: collectives even with one rank
-    if world > 1 or force_reduce:
+    # RT_BENCH_FORCE_GROUP=1 (rehearsal on a one-GPU box): take the several-GPU path even with one GPU -- under
+    # torch.distributed.run the rank path (id broadcast, rt_group_create_rank), else rt_group_create of one device
+    force_group = os.environ.get("RT_BENCH_FORCE_GROUP") == "1"
+    ranks = world > 1 or (force_group and "WORLD_SIZE" in os.environ)  # one process per GPU (torch.distributed.run)
+    n_gpus = world if ranks else args.gpus                              # else this process drives them all
+    if n_gpus < 1:
+        sys.exit("--gpus must be at least 1")
+
+    import torch
+    from raytracing_amd import abi, lib
+
+    if lib.load().rt_get_device_count() < (1 if ranks else n_gpus):
+        sys.exit(f"bench.py needs {n_gpus} GPU(s), {lib.load().rt_get_device_count()} visible: the render path has no CPU fallback")
+
+    dist = None
+    if ranks:
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # control plane only (the RCCL id, barriers, the MAX of the ranks' times): gloo over loopback.  The frames'
+        # all-reduce is the library's own RCCL communicator.
+        dist.init_process_group(os.environ.get("RT_BENCH_CONTROL_BACKEND", "gloo"))
 
     scene_path = os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc")
     scene = abi.load_scene(scene_path)
     n_objects = int(scene.nodes[scene.root]["child1"])
     cam = lib.camera((12, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 3.0 / 2.0, 0.1, 10.0)
     W, H, spp = args.width, args.height, args.spp
-
-    # One slot per frame in flight: its own HIP stream, library context (the scene is tiny: one copy per slot)
-    # and accumulation buffer.  Frame k runs entirely on slot k % n: zero -> render kernel -> all-reduce
-    # (frame.FramePipeline orders the all-reduce of frame k-1 after the launch of frame k).
-    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
-    slots = []
-    for _ in range(n_slots):
-        s = torch.cuda.Stream(device=dev)
-        c = lib.Context(local_rank, s.cuda_stream)
-        c.upload(scene)
-        with torch.cuda.stream(s):
-            buf = torch.zeros((H, W, 3), dtype=torch.int64, device=dev)
-        slots.append((s, c, buf))
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (1 if n_gpus == 1 and not force_group else 3)
 
     verbose = os.environ.get("RT_BENCH_VERBOSE") == "1"
     if verbose:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_STALL_S", "30")), exit=True)
+        faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_STALL_S", "60")), exit=True)
 
     def say(msg):
         if verbose:
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-    def reduce_fn(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-
-    class Slot:
-        def __init__(self, s, c, buf):
-            self.s, self.c, self.accum = s, c, buf
-
-        def stream(self):
-            return torch.cuda.stream(self.s)
-
-        def drain(self):
-            self.s.synchronize()
-
-        def render(self, begin, count, accum, k):
-            self.c.render_device(cam, abi.render_params(W, H, count, args.depth, seed=1 + k, sample_begin=begin),
-                                 accum.data_ptr())
-
-    pipe = frame.FramePipeline([Slot(*t) for t in slots], spp, rank, world, reduce_fn if world > 1 else None)
-    if force_reduce:
-        pipe.world, pipe.all_reduce = max(world, 2), reduce_fn
-    step = pipe.submit
+    if n_gpus == 1 and not force_group:
+        run = OneGpu(torch, lib, abi, scene, cam, W, H, spp, args.depth, n_slots)
+    elif ranks:
+        ident = torch.zeros(abi.RT_COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(lib.comm_id_create()), dtype=torch.uint8).clone()
+        dist.broadcast(ident, src=0)
+        say("RCCL id received")
+        run = ManyGpus(lib.Group(device=local_rank, rank=rank, world=world, comm_id=bytes(ident.numpy().tobytes()),
+                                 frame_slots=n_slots), abi, scene, cam, W, H, spp, args.depth)
+    else:
+        run = ManyGpus(lib.Group(devices=list(range(n_gpus)), frame_slots=n_slots), abi, scene, cam, W, H, spp, args.depth)
+    say("contexts ready")
 
     def fence():
-        pipe.flush()
-        torch.cuda.synchronize(dev)
-        if world > 1:
+        run.drain()
+        if ranks:
             dist.barrier()
-            torch.cuda.synchronize(dev)
 
-    say("contexts ready")
+    def over_ranks(value, op):
+        if not ranks:
+            return value
+        t = torch.tensor(value, dtype=torch.float64 if isinstance(value[0], float) else torch.int64)
+        dist.all_reduce(t, op=op)
+        return t.tolist()
+
     for k in range(args.warmup):
-        step(k)
-        say(f"warm-up step {k} enqueued")
+        run.submit(k)
     fence()
     say("warm-up done")
-    for _, c, _ in slots:
-        c.take_stats()  # drop warm-up statistics
+    run.take_stats()  # drop warm-up statistics
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k)
-    say("timed steps enqueued")
+        run.submit(args.warmup + k)
     fence()
     dt = time.perf_counter() - t0
     say("timed region done")
-    st = {"samples": 0, "rays": 0, "nan_samples": 0, "kernel_ms": 0.0, "kernel_launches": 0}
-    for _, c, _ in slots:
-        one = c.take_stats()
-        for key in st:
-            st[key] += one[key]
+    st = run.take_stats()
+    dt = over_ranks([dt], dist.ReduceOp.MAX if ranks else None)[0]
+    samples, rays, bad = over_ranks([st["samples"], st["rays"], st["nan_samples"]], dist.ReduceOp.SUM if ranks else None)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    counts = torch.tensor([st["samples"], st["rays"], st["nan_samples"]], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    samples, rays, bad = (int(x) for x in counts.tolist())
+    # A frame rendered alone: first launch to summed buffer complete on every GPU, K frames one after the other
+    single = None
+    if n_gpus > 1 or force_group:
+        base = args.warmup + args.steps
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            run.submit(base + k)
+            run.wait_frame(base + k)
+        fence()
+        ds = over_ranks([time.perf_counter() - t1], dist.ReduceOp.MAX if ranks else None)[0]
+        run.take_stats()
+        single = {"ms_per_frame": ds / args.steps * 1e3, "msamples_per_s": W * H * spp * args.steps / ds / 1e6,
+                  "frames": args.steps, "note": "one frame in flight: zero, render, all-reduce, host wait, then the next"}
 
     if rank == 0:
         assert samples == W * H * spp * args.steps, (samples, W * H * spp * args.steps)
         value = samples / dt / 1e6
-        # roofline of the dominant kernel (k_render_spheres) on THIS rank: algorithmic flops of its launches
-        # over their event-timed duration on the kernel's own stream
-        # (with several frames in flight launches overlap each other, so the wall time per step is used
-        # instead: an upper bound on the kernel's time, i.e. a lower bound on the fraction)
-        k_ms = st["kernel_ms"] / max(1, st["kernel_launches"]) if n_slots == 1 else dt / args.steps * 1e3
+        # roofline of the dominant kernel (k_render_spheres) on THIS process's GPUs: executed flops of its launches
+        # over their event-timed duration on the kernel's own stream (with several frames in flight launches
+        # overlap each other, so the wall time per step is used instead: an upper bound on the kernel's time,
+        # i.e. a lower bound on the fraction)
         launches = max(1, st["kernel_launches"])
+        k_ms = st["kernel_ms"] / launches if n_slots == 1 else dt / args.steps * 1e3
         reference_flop = algorithmic_flop(n_objects, st["rays"], st["samples"]) / launches
         executed = profiled_execution(n_objects)
         flop_per_launch = executed["flop_per_ray"] * st["rays"] / launches if executed else None
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12 if executed and k_ms > 0 else None
+        frac = achieved / PEAK_FP32_VALU_TFLOPS if achieved is not None else None
         traffic = profiled_traffic(W, H, spp, args.depth)
+        stale = (executed["kernel_source_sha256"] != kernel_source_sha256()) if executed else None
+        if ranks:
+            how = f"one process per GPU, {world} ranks; RCCL communicator from ncclCommInitRank"
+        elif n_gpus > 1:
+            how = f"one process driving {n_gpus} GPUs; RCCL communicators from ncclCommInitAll"
+        else:
+            how = "one GPU, no collective"
         out = {
             "metric": "Msamples/sec (paths x spp / s), One-Weekend final scene",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": value / PUBLISHED_MSAMPLES_S, "dtype": "f64 (f32 screening pass)",
             "data": "synthetic: the reference's random_scene() as rolled under g++/glibc, dumped to tests/golden/scene_c2.rtsc",
             "config": {"workload": "One Weekend final random-spheres scene (BASELINE configs[1])", "objects": n_objects,
                        "width": W, "height": H, "spp": spp, "max_depth": args.depth,
-                       "parallelism": f"spp split over {world} rank(s), one int64 all-reduce per frame",
+                       "parallelism": f"spp split over {n_gpus} GPU(s), one int64 RCCL all-reduce per frame inside the library ({how})",
                        "frames_in_flight": n_slots},
+            "value_is": "throughput over the timed frames" + ("" if n_slots == 1 else f", {n_slots} frames in flight (single_frame = a frame rendered alone)"),
+            "single_frame": single,
             "mrays_per_s": rays / dt / 1e6, "rays_per_sample": rays / max(1, samples), "nan_samples": bad,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS if achieved is not None else None,
+                         "frac": frac,
+                         "frac_active_lanes": frac * executed["lanes_active"] if frac is not None else None,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "k_render_spheres", "kernel_ms": k_ms,
                          "flop_per_launch": flop_per_launch,
                          "flop_source": executed["source"] if executed else None,
+                         "flop_source_stale": stale,
                          "fp64_share_of_flop": executed["fp64_share"] if executed else None,
                          "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,
                          "lanes_active": executed["lanes_active"] if executed else None,
@@ -303,24 +394,26 @@ def main():
                          "note": "FP32 vector roofline.  The kernel screens the list through a two-level "
                                  "structure, so flop = EXECUTED vector flops (hardware counters of the committed "
                                  "profile of this command, per ray, x this run's rays; 64 lanes per "
-                                 "wave-instruction), not the flat-list price of the reference algorithm "
+                                 "wave-instruction whether or not a lane is active: frac_active_lanes = frac x "
+                                 "the share of active lanes), not the flat-list price of the reference algorithm "
                                  "(reference_algorithm_tflops = what that price would give, context only).  "
+                                 "flop_source_stale: the kernel sources have changed since that profile was taken "
+                                 "(kernel_ms, value and the ray counts are always this run's own).  "
                                  "The kernel is bound by VALU issue (valu_issue_utilisation: share of cycles a "
                                  "SIMD issues a vector instruction), most of it double-precision, integer and "
                                  "control work that the flop count does not see.  traffic = L2 memory-side "
                                  "bytes per launch from the committed counter passes (64-bit accumulation "
                                  "atomics, absorbed by the Infinity Cache; algorithmic bytes are the 23 MB frame)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path)
             many = cpu_baseline_all_cores(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1))
             if many:
                 out["cpu_baseline_all_cores"] = many
         print(json.dumps(out), flush=True)
 
-    for _, c, _ in slots:
-        c.close()
-    if world > 1 or force_reduce:
+    run.close()
+    if ranks:
         dist.destroy_process_group()
 
 

@@ -38,7 +38,8 @@ enum {
     RT_ERR_HIP = 4,                /* a HIP runtime call failed (see rt_last_error_detail) */
     RT_ERR_NO_SCENE = 5,           /* render / first-hit called before rt_scene_upload     */
     RT_ERR_OUT_OF_MEMORY = 6,
-    RT_ERR_LIMIT = 7               /* a documented size limit was exceeded                 */
+    RT_ERR_LIMIT = 7,              /* a documented size limit was exceeded                 */
+    RT_ERR_COMM = 8                /* RCCL could not be loaded or a collective call failed  */
 };
 
 /* ------------------------------------------------------------------ scene graph
@@ -236,6 +237,11 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
 int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,
                      int64_t* d_accum_fixed);
 int rt_context_synchronize(rt_context* ctx);
+/* The hand-over of the sums to write_color (B1/RayTracing.cpp:125: `write_color(std::cout, pixel_color, ...)`) for a
+ * frame that rt_render_device left on the device: waits for the context's stream, converts the fixed-point sums
+ * d_accum_fixed[3*width*height] (DEVICE memory) to doubles on the device and copies them to the HOST array
+ * accum_rgb_out through a pinned staging buffer the context keeps.  rt_render = zero + rt_render_device + this. */
+int rt_read_sums(rt_context* ctx, const int64_t* d_accum_fixed, int width, int height, double* accum_rgb_out);
 /* Validation switch: when on, kernels skip their float screening pass and test every object
  * in double.  Results must be identical either way; only the speed differs. */
 int rt_context_set_exact_only(rt_context* ctx, int on);
@@ -263,6 +269,65 @@ int rt_context_take_stats(rt_context* ctx, rt_stats* out);
  * double with the reference's operation order; meant to be compared bit for bit.        */
 int rt_first_hit(rt_context* ctx, const rt_camera_desc* cam, int width, int height,
                  int32_t* ids_out);
+
+/* ------------------------------------------------------------------ several GPUs
+ * The reference is single-threaded; its only word on parallelism is the author's recipe "copy the code N times with
+ * different seeds onto N cores, then average the images" ("Ray Tracing In a Weekend/README.md":2538-2542).  A group
+ * is that recipe made exact: the world is replicated on every GPU, member r of n renders the samples
+ * rt_split_samples(sample_count, r, n) of every pixel (global sample indices, so the random numbers are those of the
+ * unsplit frame), and the members' fixed-point sums are added by ONE RCCL all-reduce (ncclInt64, ncclSum) per frame.
+ * Integer sums make the n-GPU frame equal the one-GPU frame bit for bit.  The group owns one RCCL communicator per
+ * local member, one HIP stream, rendering context and accumulation buffer per member and frame slot; RCCL is loaded
+ * (dlopen of librccl.so.1) when the first group is created.  A group is used from one host thread at a time.     */
+typedef struct rt_group rt_group;
+
+/* Member `index` of `n` renders samples [*begin, *begin + *count) of a frame of `sample_count` samples per pixel:
+ * the first sample_count % n members get one sample more (500 over 8: 63,63,63,63,62,62,62,62).  Host arithmetic
+ * only; bad arguments give *count = 0. */
+void rt_split_samples(int sample_count, int index, int n, int* begin, int* count);
+
+/* One process driving n GPUs (device_ordinals[n], all different): the communicators come from ncclCommInitAll.
+ * frame_slots (1..8) = frames that may be in flight at once, each on its own stream and buffers. */
+int rt_group_create(const int* device_ordinals, int n, int frame_slots, rt_group** out);
+
+/* One process per GPU: rank 0 makes an id (ncclGetUniqueId), hands its bytes to the other ranks by any means, and
+ * every rank calls rt_group_create_rank with the same id (ncclCommInitRank; collective over the ranks). */
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm_id {
+    char bytes[RT_COMM_ID_BYTES];
+} rt_comm_id;
+int rt_comm_id_create(rt_comm_id* out);
+int rt_group_create_rank(int device_ordinal, int rank, int n_ranks, const rt_comm_id* id, int frame_slots,
+                         rt_group** out);
+void rt_group_destroy(rt_group* g);
+
+int rt_group_size(const rt_group* g);        /* members over all processes (the n of rt_split_samples)          */
+int rt_group_local_count(const rt_group* g); /* members driven by this process                                  */
+int rt_group_frame_slots(const rt_group* g);
+/* The rendering context of local member `local_index` on frame slot `slot` (validation switches, statistics);
+ * owned by the group. */
+rt_context* rt_group_context(rt_group* g, int local_index, int slot);
+
+/* rt_scene_upload on every local context. */
+int rt_group_scene_upload(rt_group* g, const rt_scene_desc* scene);
+
+/* One frame of the reference render loop (as rt_render) over all members: returns when the summed frame is on the
+ * host.  params->sample_begin / sample_count describe the WHOLE frame; every process of the group must call it with
+ * the same arguments.  stats (may be NULL) sums the local members.  Uses frame slot 0. */
+int rt_group_render(rt_group* g, const rt_camera_desc* cam, const rt_render_params* params, double* accum_rgb_out,
+                    rt_stats* stats);
+/* The same frame without waiting: on slot `slot`, every local member zeroes its buffer, renders its share and joins
+ * the all-reduce, all enqueued on the slot's streams.  rt_group_wait blocks until the slot's summed frame is
+ * complete on every local member; rt_group_read then hands it over as rt_read_sums does (from local member 0);
+ * rt_group_device_sums is the buffer itself (DEVICE memory of that member's GPU, valid until the slot's next frame
+ * or rt_group_destroy).  A slot must be waited for before it is given another frame. */
+int rt_group_render_async(rt_group* g, const rt_camera_desc* cam, const rt_render_params* params, int slot);
+int rt_group_wait(rt_group* g, int slot);
+int rt_group_read(rt_group* g, int slot, double* accum_rgb_out);
+const int64_t* rt_group_device_sums(rt_group* g, int local_index, int slot);
+/* Statistics of the local members since the last call (sums over members and slots; synchronises them). */
+int rt_group_take_stats(rt_group* g, rt_stats* out);
+const char* rt_group_last_error_detail(const rt_group* g); /* g == NULL: of the last failed creation */
 
 /* Host helpers that restate small host-side pieces of the reference. */
 

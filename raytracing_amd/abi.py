@@ -22,6 +22,8 @@ RT_ERR_HIP = 4
 RT_ERR_NO_SCENE = 5
 RT_ERR_OUT_OF_MEMORY = 6
 RT_ERR_LIMIT = 7
+RT_ERR_COMM = 8
+RT_COMM_ID_BYTES = 128
 
 (RT_NODE_SPHERE, RT_NODE_MOVING_SPHERE, RT_NODE_XY_RECT, RT_NODE_XZ_RECT, RT_NODE_YZ_RECT, RT_NODE_BOX,
  RT_NODE_LIST, RT_NODE_BVH, RT_NODE_TRANSLATE, RT_NODE_ROTATE_Y, RT_NODE_MEDIUM, RT_NODE_FLIP_FACE) = range(1, 13)
@@ -74,6 +76,10 @@ class rt_camera_desc(C.Structure):
 class rt_render_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sample_begin", C.c_int32),
                 ("sample_count", C.c_int32), ("max_depth", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64)]
+
+
+class rt_comm_id(C.Structure):
+    _fields_ = [("bytes", C.c_char * RT_COMM_ID_BYTES)]
 
 
 class rt_stats(C.Structure):

@@ -1,5 +1,6 @@
 // C ABI of the library (include/raytracing_amd.h): context, scene upload, render, first hit.
-// Host code only; the kernels live in rt_kernels_*.hip.
+// Host code, plus the one-line kernel that turns fixed-point sums into doubles; the render kernels live in
+// rt_kernels_*.hip.
 //
 // A scene is laid out for one of two kernel families at upload:
 //   sphere list   root list of spheres with book-1 materials  -> rt_kernels_spheres.hip
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -63,6 +65,10 @@ struct rt_context {
     size_t accum_elems = 0;
     int32_t* d_ids = nullptr;
     size_t ids_elems = 0;
+    // staging of rt_read_sums: the sums as doubles on the device, and a pinned host buffer for the copy
+    double* d_conv = nullptr;
+    double* h_conv = nullptr;
+    size_t conv_elems = 0;
     // HIP event pairs around the render kernels launched since the last rt_context_take_stats
     std::vector<hipEvent_t> ev_pool;  // [2*i] = start, [2*i+1] = stop
     size_t ev_used = 0;               // pairs in use
@@ -970,6 +976,7 @@ const char* rt_error_string(int code) {
     case RT_ERR_NO_SCENE: return "no scene uploaded";
     case RT_ERR_OUT_OF_MEMORY: return "out of memory";
     case RT_ERR_LIMIT: return "size limit exceeded";
+    case RT_ERR_COMM: return "RCCL error";
     default: return "unknown error code";
     }
 }
@@ -1004,6 +1011,7 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 256);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 256);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream);
+    ctx->detail.reserve(512);  // later messages that fit do not allocate
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "rt_context_create");
         rt_context_destroy(ctx);
@@ -1033,6 +1041,8 @@ void rt_context_destroy(rt_context* ctx) {
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_ids);
+    (void)hipFree(ctx->d_conv);
+    if (ctx->h_conv) (void)hipHostFree(ctx->h_conv);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1135,12 +1145,11 @@ static int item_cap_for(const rt_render_params*) {
     return cap;
 }
 
-int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed) {
-    int rc = check_render_args(ctx, cam, p);
-    if (rc != RT_OK) return rc;
-    if (!d_accum_fixed) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null accumulation buffer");
-    if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // depth <= 0: every sample is black
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+// Enqueues the render kernel for a checked call on the context's stream: the samples are ADDED to d_accum_fixed; the
+// work-queue head `d_counter` is zeroed first; `d_stats` (4 counters) is added to.  `timed`: bracket the launch with an
+// event pair of the context's pool (created on demand), for rt_context_take_stats.
+static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed,
+                          uint32_t* d_counter, uint64_t* d_stats, bool timed) {
 
     const int item_cap = item_cap_for(p);
     const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
@@ -1162,11 +1171,11 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (blocks > max_useful) blocks = (int)max_useful;
     if (blocks < 1) blocks = 1;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
     // time the kernel with an event pair on its own stream (the first MAX_TIMED_LAUNCHES launches
     // after each rt_context_take_stats)
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->ev_used < MAX_TIMED_LAUNCHES) {
+    if (timed && ctx->ev_used < MAX_TIMED_LAUNCHES) {
         if (ctx->ev_pool.size() < 2 * (ctx->ev_used + 1)) {
             hipEvent_t a = nullptr, b = nullptr;
             HIP_TRY(ctx, hipEventCreate(&a));
@@ -1194,8 +1203,8 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.key1 = (uint32_t)(p->seed >> 32);
         A.exact_only = (ctx->exact_only || ctx->screen_unsafe || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
         A.accum = d_accum_fixed;
-        A.item_counter = ctx->d_counter;
-        A.stats = ctx->d_stats;
+        A.item_counter = d_counter;
+        A.stats = d_stats;
 #ifdef RT_TAIL_PROBE
         {   // debug build: per-wave timestamps of the LAST launch, dumped by rt_context_take_stats
             static uint64_t* d_probe = nullptr;
@@ -1222,8 +1231,8 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
         A.importance = importance ? 1 : 0;
         A.exact_only = (ctx->exact_only || (p->flags & RT_RENDER_EXACT_ONLY)) ? 1 : 0;
         A.accum = d_accum_fixed;
-        A.item_counter = ctx->d_counter;
-        A.stats = ctx->d_stats;
+        A.item_counter = d_counter;
+        A.stats = d_stats;
         HIP_TRY(ctx, launch_render_scene(A, blocks, ctx->stream));
     }
     if (e1) {
@@ -1233,10 +1242,57 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     return RT_OK;
 }
 
+int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed) {
+    int rc = check_render_args(ctx, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!d_accum_fixed) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null accumulation buffer");
+    if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // depth <= 0: every sample is black
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return enqueue_render(ctx, cam, p, d_accum_fixed, ctx->d_counter, ctx->d_stats, true);
+}
+
 int rt_context_synchronize(rt_context* ctx) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// fixed-point sums -> doubles: the int64 -> double conversion rounds to nearest even like the host's, and the scale
+// is a power of two, so the values are those a host loop over the copied integers would give
+__global__ void __launch_bounds__(256) k_sums_to_double(const int64_t* __restrict__ fixed, double* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (double)fixed[i] * (1.0 / (double)(1ull << RT_ACCUM_FRAC_BITS));
+}
+
+static void launch_sums_to_double(rt_context* ctx, const int64_t* d_fixed, double* d_out, size_t elems) {
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((elems + 255) / 256, (size_t)ctx->num_cus * 8));
+    hipLaunchKernelGGL(k_sums_to_double, dim3(blocks), dim3(256), 0, ctx->stream, d_fixed, d_out, elems);
+}
+
+int rt_read_sums(rt_context* ctx, const int64_t* d_accum_fixed, int width, int height, double* accum_rgb_out) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!d_accum_fixed || !accum_rgb_out) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null buffer");
+    if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 28) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad image size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t elems = (size_t)3 * width * height;
+    if (ctx->conv_elems < elems) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_conv);
+        if (ctx->h_conv) (void)hipHostFree(ctx->h_conv);
+        ctx->d_conv = nullptr;
+        ctx->h_conv = nullptr;
+        ctx->conv_elems = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_conv, elems * sizeof(double)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_conv, elems * sizeof(double), hipHostMallocDefault));
+        ctx->conv_elems = elems;
+    }
+    launch_sums_to_double(ctx, d_accum_fixed, ctx->d_conv, elems);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_conv, ctx->d_conv, elems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(accum_rgb_out, ctx->h_conv, elems * sizeof(double));
     return RT_OK;
 }
 
@@ -1318,11 +1374,8 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, elems * sizeof(int64_t), ctx->stream));
     rc = rt_render_device(ctx, cam, p, ctx->d_accum);
     if (rc != RT_OK) return rc;
-    std::vector<int64_t> fixed(elems);
-    HIP_TRY(ctx, hipMemcpyAsync(fixed.data(), ctx->d_accum, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const double inv = 1.0 / (double)(1ull << RT_ACCUM_FRAC_BITS);
-    for (size_t k = 0; k < elems; ++k) accum_rgb_out[k] = (double)fixed[k] * inv;
+    rc = rt_read_sums(ctx, ctx->d_accum, p->width, p->height, accum_rgb_out);
+    if (rc != RT_OK) return rc;
     if (stats) {
         rc = rt_context_take_stats(ctx, stats);
         if (rc != RT_OK) return rc;

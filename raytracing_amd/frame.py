@@ -12,7 +12,7 @@ from __future__ import annotations
 
 def sample_range(spp: int, rank: int, world: int):
     """Samples [begin, begin+count) of rank `rank`: the first spp % world ranks get one extra
-    (500 spp over 8 ranks -> 63,63,63,63,62,62,62,62)."""
+    (500 spp over 8 ranks -> 63,63,63,63,62,62,62,62).  The same arithmetic as the library's rt_split_samples."""
     if world < 1 or not 0 <= rank < world or spp < 0:
         raise ValueError("bad rank/world/spp")
     base, extra = divmod(spp, world)

@@ -49,6 +49,8 @@ def load():
     L.rt_render_device.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
     L.rt_context_synchronize.restype = C.c_int
     L.rt_context_synchronize.argtypes = [ctx_p]
+    L.rt_read_sums.restype = C.c_int
+    L.rt_read_sums.argtypes = [ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.rt_context_set_exact_only.restype = C.c_int
     L.rt_context_set_exact_only.argtypes = [ctx_p, C.c_int]
     L.rt_context_set_force_graph.restype = C.c_int
@@ -59,6 +61,39 @@ def load():
     L.rt_context_take_stats.argtypes = [ctx_p, C.POINTER(abi.rt_stats)]
     L.rt_first_hit.restype = C.c_int
     L.rt_first_hit.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.c_int, C.c_int, C.c_void_p]
+    grp_p = C.c_void_p
+    L.rt_split_samples.restype = None
+    L.rt_split_samples.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rt_group_create.restype = C.c_int
+    L.rt_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(grp_p)]
+    L.rt_comm_id_create.restype = C.c_int
+    L.rt_comm_id_create.argtypes = [C.POINTER(abi.rt_comm_id)]
+    L.rt_group_create_rank.restype = C.c_int
+    L.rt_group_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(abi.rt_comm_id), C.c_int, C.POINTER(grp_p)]
+    L.rt_group_destroy.restype = None
+    L.rt_group_destroy.argtypes = [grp_p]
+    for name in ("rt_group_size", "rt_group_local_count", "rt_group_frame_slots"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [grp_p]
+    L.rt_group_context.restype = ctx_p
+    L.rt_group_context.argtypes = [grp_p, C.c_int, C.c_int]
+    L.rt_group_scene_upload.restype = C.c_int
+    L.rt_group_scene_upload.argtypes = [grp_p, C.POINTER(abi.rt_scene_desc)]
+    L.rt_group_render.restype = C.c_int
+    L.rt_group_render.argtypes = [grp_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p,
+                                  C.POINTER(abi.rt_stats)]
+    L.rt_group_render_async.restype = C.c_int
+    L.rt_group_render_async.argtypes = [grp_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_int]
+    L.rt_group_wait.restype = C.c_int
+    L.rt_group_wait.argtypes = [grp_p, C.c_int]
+    L.rt_group_read.restype = C.c_int
+    L.rt_group_read.argtypes = [grp_p, C.c_int, C.c_void_p]
+    L.rt_group_device_sums.restype = C.c_void_p
+    L.rt_group_device_sums.argtypes = [grp_p, C.c_int, C.c_int]
+    L.rt_group_take_stats.restype = C.c_int
+    L.rt_group_take_stats.argtypes = [grp_p, C.POINTER(abi.rt_stats)]
+    L.rt_group_last_error_detail.restype = C.c_char_p
+    L.rt_group_last_error_detail.argtypes = [grp_p]
     L.rt_camera_init.restype = None
     L.rt_camera_init.argtypes = [C.POINTER(abi.rt_camera_desc), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double)] + [C.c_double] * 6
@@ -79,6 +114,10 @@ EXPORTED_SYMBOLS = [
     "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_set_force_graph",
     "rt_context_take_stats", "rt_context_kernels_for",
     "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
+    "rt_read_sums", "rt_split_samples", "rt_group_create", "rt_comm_id_create", "rt_group_create_rank", "rt_group_destroy",
+    "rt_group_size", "rt_group_local_count", "rt_group_frame_slots", "rt_group_context", "rt_group_scene_upload",
+    "rt_group_render", "rt_group_render_async", "rt_group_wait", "rt_group_read", "rt_group_device_sums",
+    "rt_group_take_stats", "rt_group_last_error_detail",
 ]
 
 
@@ -110,6 +149,23 @@ def stats_dict(st: abi.rt_stats) -> dict:
     return {"samples": int(st.samples), "rays": int(st.rays), "nan_samples": int(st.nan_samples),
             "overflow_rays": int(st.overflow_rays), "kernel_launches": int(st.kernel_launches),
             "kernel_ms": float(st.kernel_ms)}
+
+
+def split_samples(spp: int, index: int, n: int):
+    """rt_split_samples: samples [begin, begin + count) of member `index` of `n` (host arithmetic, no GPU needed)."""
+    b, c = C.c_int(), C.c_int()
+    load().rt_split_samples(int(spp), int(index), int(n), C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+def comm_id_create() -> bytes:
+    """rt_comm_id_create: the 128 bytes rank 0 hands to every rank of a one-process-per-GPU group."""
+    cid = abi.rt_comm_id()
+    L = load()
+    rc = L.rt_comm_id_create(C.byref(cid))
+    if rc != 0:
+        raise RtError(rc, "rt_comm_id_create", L.rt_group_last_error_detail(None).decode())
+    return bytes(C.string_at(C.addressof(cid), abi.RT_COMM_ID_BYTES))
 
 
 class Context:
@@ -176,6 +232,13 @@ class Context:
     def synchronize(self):
         self._check(self._L.rt_context_synchronize(self._h), "rt_context_synchronize")
 
+    def read_sums(self, d_accum_ptr: int, width, height) -> np.ndarray:
+        """rt_read_sums: device fixed-point sums -> host doubles [H,W,3] (waits for the context's stream)."""
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        self._check(self._L.rt_read_sums(self._h, C.c_void_p(d_accum_ptr), int(width), int(height), out.ctypes.data),
+                    "rt_read_sums")
+        return out
+
     def take_stats(self) -> dict:
         st = abi.rt_stats()
         self._check(self._L.rt_context_take_stats(self._h, C.byref(st)), "rt_context_take_stats")
@@ -186,3 +249,113 @@ class Context:
         self._check(self._L.rt_first_hit(self._h, C.byref(cam), int(width), int(height), ids.ctypes.data),
                     "rt_first_hit")
         return ids
+
+
+class _BorrowedContext(Context):
+    """A context owned by a group: same methods, never destroyed from here."""
+
+    def __init__(self, handle):
+        self._L = load()
+        self._h = C.c_void_p(handle)
+        self._scene = None
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class Group:
+    """Several GPUs rendering one frame; mirrors the rt_group_* entry points.
+
+    Group(devices=[0, 1, ...])                      one process driving all of them (ncclCommInitAll)
+    Group(device=d, rank=r, world=n, comm_id=b)     one process per GPU (ncclCommInitRank); `b` from comm_id_create()
+                                                    on rank 0, handed to every rank by the caller
+    """
+
+    def __init__(self, devices=None, *, device=None, rank=None, world=None, comm_id=None, frame_slots=1):
+        self._L = load()
+        self._h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._L.rt_group_create(arr, len(devices), int(frame_slots), C.byref(self._h))
+            what = "rt_group_create"
+        else:
+            cid = abi.rt_comm_id()
+            C.memmove(C.addressof(cid), comm_id, abi.RT_COMM_ID_BYTES)
+            rc = self._L.rt_group_create_rank(int(device), int(rank), int(world), C.byref(cid), int(frame_slots),
+                                              C.byref(self._h))
+            what = "rt_group_create_rank"
+        if rc != 0:
+            raise RtError(rc, what, self._L.rt_group_last_error_detail(None).decode())
+        self._scene = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(rc, what, self._L.rt_group_last_error_detail(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.rt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self) -> int:
+        return int(self._L.rt_group_size(self._h))
+
+    @property
+    def local_count(self) -> int:
+        return int(self._L.rt_group_local_count(self._h))
+
+    @property
+    def frame_slots(self) -> int:
+        return int(self._L.rt_group_frame_slots(self._h))
+
+    def context(self, local_index=0, slot=0) -> Context:
+        h = self._L.rt_group_context(self._h, int(local_index), int(slot))
+        if not h:
+            raise IndexError("no such member / slot")
+        return _BorrowedContext(h)
+
+    def upload(self, scene: abi.Scene):
+        d = scene.desc()
+        self._check(self._L.rt_group_scene_upload(self._h, C.byref(d)), "rt_group_scene_upload")
+        self._scene = scene
+
+    def render(self, cam, params):
+        """-> (double colour sums [H,W,3] of the whole frame, stats dict of the local members)"""
+        out = np.zeros((params.height, params.width, 3), dtype=np.float64)
+        st = abi.rt_stats()
+        self._check(self._L.rt_group_render(self._h, C.byref(cam), C.byref(params), out.ctypes.data, C.byref(st)),
+                    "rt_group_render")
+        return out, stats_dict(st)
+
+    def render_async(self, cam, params, slot=0):
+        self._check(self._L.rt_group_render_async(self._h, C.byref(cam), C.byref(params), int(slot)),
+                    "rt_group_render_async")
+
+    def wait(self, slot=0):
+        self._check(self._L.rt_group_wait(self._h, int(slot)), "rt_group_wait")
+
+    def read(self, width, height, slot=0) -> np.ndarray:
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        self._check(self._L.rt_group_read(self._h, int(slot), out.ctypes.data), "rt_group_read")
+        return out
+
+    def device_sums(self, local_index=0, slot=0) -> int:
+        return int(self._L.rt_group_device_sums(self._h, int(local_index), int(slot)) or 0)
+
+    def take_stats(self) -> dict:
+        st = abi.rt_stats()
+        self._check(self._L.rt_group_take_stats(self._h, C.byref(st)), "rt_group_take_stats")
+        return stats_dict(st)

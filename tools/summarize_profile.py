@@ -93,7 +93,9 @@ def main():
         command = "python3 tools/bench_scenes.py <spp> <scene>"
         title = f"tools/bench_scenes.py ({out_name})"
         script = "tools/profile_scene.sh"
-    summary = {"tag": tag, "command": command + " (under rocprofv3)",
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_sha256  # the tree the library under the profiler was built from
+    summary = {"tag": tag, "command": command + " (under rocprofv3)", "kernel_source_sha256": kernel_source_sha256(),
                "kernel_stats": stats_rows, "bench_line_under_profiler": bench if bench is not None else bench_text,
                "counters_per_launch": counters, "derived": derived}
     with open(os.path.join(out_dir, f"{tag}_{out_name}.json"), "w") as fp:
