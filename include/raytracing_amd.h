@@ -242,6 +242,19 @@ int rt_context_synchronize(rt_context* ctx);
  * d_accum_fixed[3*width*height] (DEVICE memory) to doubles on the device and copies them to the HOST array
  * accum_rgb_out through a pinned staging buffer the context keeps.  rt_render = zero + rt_render_device + this. */
 int rt_read_sums(rt_context* ctx, const int64_t* d_accum_fixed, int width, int height, double* accum_rgb_out);
+/* rt_render's work without a single allocation.  It has no counterpart in the reference; it exists for callers that
+ * cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The
+ * samples of the call are summed in a scratch frame that lives in the library's code object (a file-scope device
+ * array of 256 + 24 * RT_NOALLOC_MAX_PIXELS bytes, about 24 MiB, which every GPU the library runs on holds until the
+ * process ends) and leave as DOUBLE sums in the caller's DEVICE buffer d_accum_rgb_out[3*width*height] (row 0 = top,
+ * r,g,b; overwritten, not added to).  Enqueued on the context's stream: rt_context_synchronize waits.  The call makes
+ * no hipMalloc, hipFree, event creation or other allocating call, and no host allocation when it succeeds; it
+ * returns RT_ERR_LIMIT when width*height exceeds RT_NOALLOC_MAX_PIXELS.  All contexts of one GPU share that GPU's
+ * array: calls that overlap in time on one GPU race (calls on one stream, or on one context, never overlap).  Its
+ * launches are not timed and its samples and rays are not reported by rt_context_take_stats. */
+#define RT_NOALLOC_MAX_PIXELS (1 << 20)
+int rt_render_noalloc(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,
+                      double* d_accum_rgb_out);
 /* Validation switch: when on, kernels skip their float screening pass and test every object
  * in double.  Results must be identical either way; only the speed differs. */
 int rt_context_set_exact_only(rt_context* ctx, int on);

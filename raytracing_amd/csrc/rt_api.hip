@@ -69,6 +69,7 @@ struct rt_context {
     double* d_conv = nullptr;
     double* h_conv = nullptr;
     size_t conv_elems = 0;
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of `scratch` (rt_render_noalloc)
     // HIP event pairs around the render kernels launched since the last rt_context_take_stats
     std::vector<hipEvent_t> ev_pool;  // [2*i] = start, [2*i+1] = stop
     size_t ev_used = 0;               // pairs in use
@@ -76,11 +77,28 @@ struct rt_context {
 
 static constexpr size_t MAX_TIMED_LAUNCHES = 256;
 
+// Scratch of rt_render_noalloc: device memory the kernels need beyond the caller's buffers, held in the code object
+// instead of coming from hipMalloc.  [0, 4) work-queue head, [64, 96) the four statistics counters,
+// [NOALLOC_HEADER, ...) the fixed-point frame the samples are summed in before they leave as doubles.
+// `scratch` is a host-side stand-in for the symbol: host code only ever uses the per-device address that
+// hipGetSymbolAddress returned (every GPU holds its own copy of the array at its own address).
+static constexpr size_t NOALLOC_HEADER = 256;
+static constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_HEADER + (size_t)3 * RT_NOALLOC_MAX_PIXELS * sizeof(int64_t);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static constexpr int MAX_DEVICES = 64;
+static unsigned char* g_scratch_of_device[MAX_DEVICES];  // filled by rt_context_create, once per device
+static std::mutex g_scratch_mutex;
+
 static thread_local std::string g_create_detail;
 
 static int fail(rt_context* ctx, int code, const std::string& what) {
     if (ctx) ctx->detail = what;
     else g_create_detail = what;
+    return code;
+}
+// the same without building a std::string: a message that fits the capacity reserved at creation allocates nothing
+static int fail_c(rt_context* ctx, int code, const char* what) {
+    if (ctx) ctx->detail.assign(what);
     return code;
 }
 static int hip_fail(rt_context* ctx, hipError_t e, const char* where) {
@@ -1011,6 +1029,16 @@ int rt_context_create(int device_ordinal, void* stream, rt_context** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counter, 256);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 256);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_stats, 0, 256, ctx->stream);
+    if (e == hipSuccess && device_ordinal < MAX_DEVICES) {
+        // the address of this device's copy of the scratch array, looked up once per device with that device current
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_of_device[device_ordinal]) {
+            void* ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_of_device[device_ordinal] = (unsigned char*)ptr;
+        }
+        ctx->noalloc_scratch = g_scratch_of_device[device_ordinal];
+    }
     ctx->detail.reserve(512);  // later messages that fit do not allocate
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "rt_context_create");
@@ -1249,6 +1277,32 @@ int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render
     if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // depth <= 0: every sample is black
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return enqueue_render(ctx, cam, p, d_accum_fixed, ctx->d_counter, ctx->d_stats, true);
+}
+
+static void launch_sums_to_double(rt_context* ctx, const int64_t* d_fixed, double* d_out, size_t elems);
+
+int rt_render_noalloc(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, double* d_accum_rgb_out) {
+    int rc = check_render_args(ctx, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!d_accum_rgb_out) return fail_c(ctx, RT_ERR_INVALID_ARGUMENT, "null output buffer");
+    if (!ctx->noalloc_scratch) return fail_c(ctx, RT_ERR_NO_DEVICE, "this device has no scratch array (device ordinal beyond 63)");
+    const int64_t npix = (int64_t)p->width * p->height;
+    if (npix > (int64_t)RT_NOALLOC_MAX_PIXELS)
+        return fail_c(ctx, RT_ERR_LIMIT, "rt_render_noalloc: width*height exceeds RT_NOALLOC_MAX_PIXELS (the scratch frame is fixed-size); use rt_render_device");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Every call on this GPU shares the array and finds the last call's contents in it: the queue head, the counters
+    // and the part of the frame this call sums in all start from zero.
+    unsigned char* base = ctx->noalloc_scratch;
+    const size_t elems = (size_t)3 * (size_t)npix;
+    HIP_TRY(ctx, hipMemsetAsync(base, 0, NOALLOC_HEADER + elems * sizeof(int64_t), ctx->stream));
+    int64_t* frame = (int64_t*)(base + NOALLOC_HEADER);
+    if (p->sample_count > 0 && p->max_depth > 0) {
+        rc = enqueue_render(ctx, cam, p, frame, (uint32_t*)base, (uint64_t*)(base + 64), false);
+        if (rc != RT_OK) return rc;
+    }
+    launch_sums_to_double(ctx, frame, d_accum_rgb_out, elems);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
 }
 
 int rt_context_synchronize(rt_context* ctx) {

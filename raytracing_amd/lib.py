@@ -49,6 +49,8 @@ def load():
     L.rt_render_device.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
     L.rt_context_synchronize.restype = C.c_int
     L.rt_context_synchronize.argtypes = [ctx_p]
+    L.rt_render_noalloc.restype = C.c_int
+    L.rt_render_noalloc.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
     L.rt_read_sums.restype = C.c_int
     L.rt_read_sums.argtypes = [ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.rt_context_set_exact_only.restype = C.c_int
@@ -114,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_set_force_graph",
     "rt_context_take_stats", "rt_context_kernels_for",
     "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
-    "rt_read_sums", "rt_split_samples", "rt_group_create", "rt_comm_id_create", "rt_group_create_rank", "rt_group_destroy",
+    "rt_render_noalloc", "rt_read_sums", "rt_split_samples", "rt_group_create", "rt_comm_id_create", "rt_group_create_rank", "rt_group_destroy",
     "rt_group_size", "rt_group_local_count", "rt_group_frame_slots", "rt_group_context", "rt_group_scene_upload",
     "rt_group_render", "rt_group_render_async", "rt_group_wait", "rt_group_read", "rt_group_device_sums",
     "rt_group_take_stats", "rt_group_last_error_detail",
@@ -228,6 +230,11 @@ class Context:
         """Enqueue a render that ADDS fixed-point sums into device memory at `d_accum_ptr`."""
         self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_accum_ptr)),
                     "rt_render_device")
+
+    def render_noalloc(self, cam, params, d_out_ptr: int):
+        """rt_render_noalloc: enqueue a render that leaves DOUBLE sums in device memory at `d_out_ptr`."""
+        self._check(self._L.rt_render_noalloc(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_out_ptr)),
+                    "rt_render_noalloc")
 
     def synchronize(self):
         self._check(self._L.rt_context_synchronize(self._h), "rt_context_synchronize")
