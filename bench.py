@@ -195,6 +195,20 @@ class OneGpu:
             c.close()
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator is made; this program's stdout carries one
+    JSON line and nothing else, so file descriptor 1 points at stderr while a group is created."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class ManyGpus:
     """N > 1: an rt_group (this process's members of it); frames go round its slots."""
 
@@ -292,13 +306,17 @@ def main():
     elif ranks:
         ident = torch.zeros(abi.RT_COMM_ID_BYTES, dtype=torch.uint8)
         if rank == 0:
-            ident = torch.frombuffer(bytearray(lib.comm_id_create()), dtype=torch.uint8).clone()
+            with stdout_to_stderr():
+                ident = torch.frombuffer(bytearray(lib.comm_id_create()), dtype=torch.uint8).clone()
         dist.broadcast(ident, src=0)
         say("RCCL id received")
-        run = ManyGpus(lib.Group(device=local_rank, rank=rank, world=world, comm_id=bytes(ident.numpy().tobytes()),
-                                 frame_slots=n_slots), abi, scene, cam, W, H, spp, args.depth)
+        with stdout_to_stderr():
+            group = lib.Group(device=local_rank, rank=rank, world=world, comm_id=bytes(ident.numpy().tobytes()), frame_slots=n_slots)
+        run = ManyGpus(group, abi, scene, cam, W, H, spp, args.depth)
     else:
-        run = ManyGpus(lib.Group(devices=list(range(n_gpus)), frame_slots=n_slots), abi, scene, cam, W, H, spp, args.depth)
+        with stdout_to_stderr():
+            group = lib.Group(devices=list(range(n_gpus)), frame_slots=n_slots)
+        run = ManyGpus(group, abi, scene, cam, W, H, spp, args.depth)
     say("contexts ready")
 
     def fence():

@@ -1325,23 +1325,30 @@ static void launch_sums_to_double(rt_context* ctx, const int64_t* d_fixed, doubl
     hipLaunchKernelGGL(k_sums_to_double, dim3(blocks), dim3(256), 0, ctx->stream, d_fixed, d_out, elems);
 }
 
+// Staging of rt_read_sums for frames of `elems` values.  The buffers are never in flight when a call returns
+// (rt_read_sums ends with a stream wait), so growing them needs no synchronisation -- rt_render grows them while its
+// kernel is running.
+static int ensure_staging(rt_context* ctx, size_t elems) {
+    if (ctx->conv_elems >= elems) return RT_OK;
+    (void)hipFree(ctx->d_conv);
+    if (ctx->h_conv) (void)hipHostFree(ctx->h_conv);
+    ctx->d_conv = nullptr;
+    ctx->h_conv = nullptr;
+    ctx->conv_elems = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_conv, elems * sizeof(double)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_conv, elems * sizeof(double), hipHostMallocDefault));
+    ctx->conv_elems = elems;
+    return RT_OK;
+}
+
 int rt_read_sums(rt_context* ctx, const int64_t* d_accum_fixed, int width, int height, double* accum_rgb_out) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!d_accum_fixed || !accum_rgb_out) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null buffer");
     if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 28) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad image size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t elems = (size_t)3 * width * height;
-    if (ctx->conv_elems < elems) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_conv);
-        if (ctx->h_conv) (void)hipHostFree(ctx->h_conv);
-        ctx->d_conv = nullptr;
-        ctx->h_conv = nullptr;
-        ctx->conv_elems = 0;
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_conv, elems * sizeof(double)));
-        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_conv, elems * sizeof(double), hipHostMallocDefault));
-        ctx->conv_elems = elems;
-    }
+    const int rc = ensure_staging(ctx, elems);
+    if (rc != RT_OK) return rc;
     launch_sums_to_double(ctx, d_accum_fixed, ctx->d_conv, elems);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_conv, ctx->d_conv, elems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1428,6 +1435,7 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, elems * sizeof(int64_t), ctx->stream));
     rc = rt_render_device(ctx, cam, p, ctx->d_accum);
     if (rc != RT_OK) return rc;
+    if ((rc = ensure_staging(ctx, elems)) != RT_OK) return rc;  // a first call allocates while the kernel runs
     rc = rt_read_sums(ctx, ctx->d_accum, p->width, p->height, accum_rgb_out);
     if (rc != RT_OK) return rc;
     if (stats) {
