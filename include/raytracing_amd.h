@@ -192,11 +192,16 @@ enum {
 /* Colour sums are accumulated in 64-bit fixed point so that the sum over samples does not
  * depend on the order in which lanes, waves or GPUs add them: value = fixed * 2^-RT_ACCUM_FRAC_BITS. */
 #define RT_ACCUM_FRAC_BITS 36
+/* Range of the format.  A sample enters the sum only if every channel is below RT_ACCUM_SAMPLE_LIMIT in magnitude
+ * (2^26: its fixed-point image fits 63 bits with room to spare); any other sample -- NaN and infinities included -- is
+ * dropped and counted in rt_stats.nan_samples.  A pixel's SUM over all samples must stay below 2^27 in magnitude (the
+ * 64-bit sum wraps beyond; with the reference's lights of at most 15 that is 9 million samples per pixel). */
+#define RT_ACCUM_SAMPLE_LIMIT 67108864.0
 
 typedef struct rt_stats {
     uint64_t samples;       /* camera rays started                                   */
     uint64_t rays;          /* world.hit() calls (ray segments), as the reference counts them */
-    uint64_t nan_samples;   /* samples whose colour was NaN/Inf and was dropped      */
+    uint64_t nan_samples;   /* samples dropped: NaN, Inf or beyond RT_ACCUM_SAMPLE_LIMIT */
     uint64_t overflow_rays; /* rays that took the slow exact path (candidate list full) */
     uint64_t kernel_launches; /* render kernel launches timed into kernel_ms (at most 256 per take) */
     double kernel_ms;       /* summed device time of those launches, HIP events on the kernel's stream */

@@ -797,7 +797,9 @@ static void render_rows(render_job* jb) {
                            : ray_color(jb->s, &g, r, prm->max_depth, jb->assoc, &jb->rays);
                 pixel_color = vadd(pixel_color, c);
                 if (jb->fixed) {
-                    if (isfinite(c.e[0]) && isfinite(c.e[1]) && isfinite(c.e[2])) {
+                    /* the accumulation format's range (raytracing_amd.h): NaN, Inf and huge samples are dropped */
+                    if (fabs(c.e[0]) < RT_ACCUM_SAMPLE_LIMIT && fabs(c.e[1]) < RT_ACCUM_SAMPLE_LIMIT &&
+                        fabs(c.e[2]) < RT_ACCUM_SAMPLE_LIMIT) {
                         for (int k = 0; k < 3; ++k) fx[k] += to_fixed(c.e[k]);
                     } else {
                         jb->nan_samples++;

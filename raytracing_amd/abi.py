@@ -13,6 +13,7 @@ import numpy as np
 
 RT_ABI_VERSION = 1
 RT_ACCUM_FRAC_BITS = 36
+RT_ACCUM_SAMPLE_LIMIT = 67108864.0
 
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT = 1

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -827,7 +828,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     }
     // BVH subtrees of static spheres and boxes directly under a top-level object's instance chain become leaf sets
     std::vector<LeafSetDev> sets;
-    std::vector<int32_t> set_nodes;
+    std::vector<int32_t> set_nodes, set_order;
     // eight times the largest coordinate that appears in the world: room for instance offsets and for a camera
     // outside the objects; rays that start farther out skip the boxes' float screen
     double world_extent = 0.0;
@@ -860,11 +861,13 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true};
             SphereSetWalk::Box box;
             if (!w.walk(idx, i, box) || (int)prims.size() < ctx->subtree_set_min) continue;
-            std::vector<int> spheres, boxes;
+            std::vector<int> spheres, boxes, sphere_order, box_order;  // order = position in the tree's depth-first walk
             double coord_max = 0.0;
-            for (int id : prims) {
+            for (size_t k = 0; k < prims.size(); ++k) {
+                const int id = prims[k];
                 const rt_node& leaf = sc->nodes[id];
                 (leaf.kind == RT_NODE_BOX ? boxes : spheres).push_back(id);
+                (leaf.kind == RT_NODE_BOX ? box_order : sphere_order).push_back((int)k);
                 if (leaf.kind == RT_NODE_BOX)
                     for (int k = 0; k < 6; ++k) coord_max = std::fmax(coord_max, std::fabs(leaf.p[k]));
             }
@@ -881,6 +884,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             sets.push_back(sd);
             set_nodes.insert(set_nodes.end(), spheres.begin(), spheres.end());
             set_nodes.insert(set_nodes.end(), boxes.begin(), boxes.end());
+            set_order.insert(set_order.end(), sphere_order.begin(), sphere_order.end());
+            set_order.insert(set_order.end(), box_order.begin(), box_order.end());
         }
     }
     std::vector<TopEntry> tops;
@@ -944,6 +949,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     G.n_tops = (int32_t)tops.size();
     if ((rc = to_device(ctx, sets, &G.sets)) != RT_OK) return rc;
     if ((rc = to_device(ctx, set_nodes, &G.set_nodes)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, set_order, &G.set_order)) != RT_OK) return rc;
     std::vector<int32_t> lights;
     bool isotropic = false;
     for (int i = 0; i < sc->n_materials; ++i) isotropic = isotropic || sc->materials[i].kind == RT_MAT_ISOTROPIC;
@@ -1085,6 +1091,22 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     if (sc->nodes[sc->root].kind != RT_NODE_LIST) return fail(ctx, RT_ERR_UNSUPPORTED_SCENE, "root must be a hittable_list");
     if (sc->sky_mode != RT_SKY_GRADIENT && sc->sky_mode != RT_SKY_BACKGROUND)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad sky_mode");
+    // every array is walked in full at upload, reachable from the root or not: counts and pointers must agree
+    if (sc->n_children < 0 || sc->n_materials < 0 || sc->n_textures < 0 || sc->n_perlins < 0 || sc->n_images < 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative array count");
+    if ((sc->n_children > 0 && !sc->children) || (sc->n_materials > 0 && !sc->materials) || (sc->n_textures > 0 && !sc->textures) ||
+        (sc->n_perlins > 0 && !sc->perlins) || (sc->n_images > 0 && !sc->images))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "an array with a non-zero count is null");
+    // perlin::noise indexes ranvec[perm_x ^ perm_y ^ perm_z] (B2/perlin.h:41-43): entries are 0..255
+    for (int i = 0; i < sc->n_perlins; ++i)
+        for (int k = 0; k < 256; ++k) {
+            const rt_perlin& pn = sc->perlins[i];
+            if ((pn.perm_x[k] | pn.perm_y[k] | pn.perm_z[k]) & ~255)
+                return fail(ctx, RT_ERR_INVALID_ARGUMENT, "perlin permutation entry outside 0..255");
+        }
+    for (int i = 0; i < sc->n_images; ++i)
+        if (sc->images[i].width < 0 || sc->images[i].height < 0 || (int64_t)sc->images[i].width * sc->images[i].height > (int64_t)1 << 28)
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad image size");
 
     GraphCheck chk;
     chk.sc = sc;
@@ -1115,16 +1137,22 @@ int rt_scene_upload(rt_context* ctx, const rt_scene_desc* sc) {
     free_scene(ctx);
     ctx->spheres_timed = false;
     int rc;
-    std::vector<int> prims, tops;
-    const bool list_kernels = !ctx->force_graph && sc->lights_plus1 == 0;
-    if (list_kernels && is_book1_sphere_list(sc)) {
-        const rt_node& root = sc->nodes[sc->root];
-        prims.assign(sc->children + root.child0, sc->children + root.child0 + root.child1);
-        rc = upload_sphere_list(ctx, sc, prims, nullptr);
-    } else {
-        rc = upload_graph(ctx, sc, chk);
-        if (rc == RT_OK && list_kernels && collect_sphere_set(sc, ctx->sphere_set_max, prims, tops))
-            rc = upload_sphere_list(ctx, sc, prims, &tops);
+    try {  // host containers sized by the caller's counts: no exception leaves the C boundary
+        std::vector<int> prims, tops;
+        const bool list_kernels = !ctx->force_graph && sc->lights_plus1 == 0;
+        if (list_kernels && is_book1_sphere_list(sc)) {
+            const rt_node& root = sc->nodes[sc->root];
+            prims.assign(sc->children + root.child0, sc->children + root.child0 + root.child1);
+            rc = upload_sphere_list(ctx, sc, prims, nullptr);
+        } else {
+            rc = upload_graph(ctx, sc, chk);
+            if (rc == RT_OK && list_kernels && collect_sphere_set(sc, ctx->sphere_set_max, prims, tops))
+                rc = upload_sphere_list(ctx, sc, prims, &tops);
+        }
+    } catch (const std::bad_alloc&) {
+        rc = fail(ctx, RT_ERR_OUT_OF_MEMORY, "host memory for the scene layout");
+    } catch (const std::exception& e) {
+        rc = fail(ctx, RT_ERR_INVALID_ARGUMENT, std::string("scene layout: ") + e.what());
     }
     if (rc != RT_OK) free_scene(ctx);
     return rc;

@@ -199,6 +199,7 @@ struct SceneDev {
     const ImageDev* images;
     const LeafSetDev* sets;    // one per DEV_NODE_LEAF_SET node: the screening images of its leaves
     const int32_t* set_nodes;  // node ids of the leaves of all sets: per set its spheres, then its boxes
+    const int32_t* set_order;  // same slots: the leaf's position in the depth-first walk of its subtree (tie rule)
     int32_t sky_mode;
     int32_t n_lights;                  // light shapes sampled under RT_RENDER_IMPORTANCE
     int32_t lights[MAX_LIGHT_SHAPES];  // their node ids (xz_rect or sphere, world space)

@@ -416,7 +416,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         const double loc_a = len2(loc.d);
                         uint16_t* list = (uint16_t*)stack;
                         uint32_t* rows = stack + CAND_CAP * 32;
-                        int winner = -1;
+                        int winner = -1, sphere_j = 0;
                         double best_t = h.t;
                         if (set.spheres.n > 0) {
                             uint32_t overflowed = 0;
@@ -433,7 +433,10 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 }
                             });
                             best_t = sh.t;
-                            if (sh.id >= 0) winner = sh.aux;
+                            if (sh.id >= 0) {
+                                winner = sh.aux;
+                                sphere_j = sh.id;
+                            }
                             PROBE_MARK(PS_SET_SPHERES);
                         }
                         if constexpr ((F & F_RECT) != 0) {
@@ -447,8 +450,16 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                         best.aux = bn.c + side;
                                     }
                                 });
-                                best_t = bh.t;
-                                if (bh.id >= 0) winner = bh.aux;
+                                // A box side hit at exactly the sphere's t: bvh_node::hit accepts an equal root
+                                // (B2/bvh.h:99-100, B2/sphere.h:54), so the leaf the tree reaches LATER wins -- the
+                                // sphere keeps the hit if it comes after the box in the depth-first walk.
+                                bool box_wins = bh.id >= 0;
+                                if (box_wins && winner >= 0 && bh.t == best_t)
+                                    box_wins = S.set_order[first_box + bh.id] > S.set_order[first_slot + sphere_j];
+                                if (box_wins) {
+                                    best_t = bh.t;
+                                    winner = bh.aux;
+                                }
                                 PROBE_MARK(PS_SET_BOXES);
                             }
                         }

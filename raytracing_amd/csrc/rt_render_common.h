@@ -313,10 +313,11 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
     return ballot(active || w.has_item) != 0ull;
 }
 
-// Converts one sample colour to 2^-RT_ACCUM_FRAC_BITS fixed point and adds it; a non-finite colour is
-// dropped and counted (the reference would carry the NaN into its image).
+// Converts one sample colour to 2^-RT_ACCUM_FRAC_BITS fixed point and adds it.  A colour the format cannot hold --
+// a channel of RT_ACCUM_SAMPLE_LIMIT or more in magnitude, an infinity, a NaN (every comparison with one is false) --
+// is dropped and counted (the reference would carry it into its image).
 __device__ __forceinline__ void add_sample(d3 c, int64_t& fx, int64_t& fy, int64_t& fz, uint32_t& n_bad) {
-    if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) {
+    if (fabs(c.x) < RT_ACCUM_SAMPLE_LIMIT && fabs(c.y) < RT_ACCUM_SAMPLE_LIMIT && fabs(c.z) < RT_ACCUM_SAMPLE_LIMIT) {
         fx += __double2ll_rn(c.x * ACCUM_SCALE);
         fy += __double2ll_rn(c.y * ACCUM_SCALE);
         fz += __double2ll_rn(c.z * ACCUM_SCALE);

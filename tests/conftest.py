@@ -78,3 +78,24 @@ def make_sphere_scene(spheres, materials, sky_mode=abi.RT_SKY_GRADIENT, backgrou
     textures = np.array(texs, dtype=abi.TEXTURE_DTYPE) if texs else np.zeros(0, dtype=abi.TEXTURE_DTYPE)
     return abi.Scene(0, nodes, children, mats, textures, np.zeros(0, dtype=abi.PERLIN_DTYPE), [], sky_mode,
                      tuple(background))
+
+
+# Worlds whose arithmetic calls log / sin / cos / acos / atan2 (media, noise and image textures, sphere uv, book 3's
+# light sampling): the device's libm is within one ulp of glibc's (two for atan2) but not identical, and a last-bit
+# difference in a hit distance or a texture coordinate moves a sample by ~1e-16 of its value.  Samples are rounded to
+# 2^-36 before they are summed, so kernel and oracle still agree unless a sample sits within that distance of a rounding
+# boundary: measured about 40 one-unit differences in a thousand million samples.  The contract for such worlds is:
+# at most LIBM_MAX_VALUES values per render off by at most LIBM_MAX_UNITS units of 2^-36 (ray counts are asserted
+# exactly where the test has them).  Every other world -- configurations 1 to 3 among them -- is held to exact equality.
+LIBM_MAX_UNITS, LIBM_MAX_VALUES = 2, 4
+
+
+def assert_sums_match(got, want, libm_world, what=None):
+    """got, want: double colour sums [H, W, 3] of the kernel and of the oracle."""
+    if not libm_world:
+        assert np.array_equal(got, want), (what, np.abs(got - want).max())
+        return
+    frac = 2.0 ** abi.RT_ACCUM_FRAC_BITS
+    units = np.abs(np.rint(got * frac) - np.rint(want * frac))
+    assert units.max() <= LIBM_MAX_UNITS and np.count_nonzero(units) <= LIBM_MAX_VALUES, \
+        (what, units.max(), np.count_nonzero(units))

@@ -8,7 +8,7 @@ import pytest
 
 from raytracing_amd import abi, lib
 from tests import oracle_binding as ob
-from tests.conftest import gold
+from tests.conftest import assert_sums_match, gold
 
 pytestmark = pytest.mark.gpu
 FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
@@ -199,7 +199,7 @@ def test_random_world_matches_oracle(seed, monkeypatch):
             c.close()
         assert np.array_equal(got, exact), (seed, set_min)
         assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, set_min)
-        assert np.array_equal(got, want), (seed, set_min, np.abs(got - want).max())
+        assert_sums_match(got, want, True, (seed, set_min))
         assert np.array_equal(ids, want_ids), (seed, set_min)
 
 
@@ -270,7 +270,7 @@ def test_random_sphere_world_matches_oracle(seed):
     finally:
         c.close()
     assert st["rays"] == ost["rays"], seed
-    assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, t0, t1)
+    assert_sums_match(got, fixed.astype(np.float64) / FRAC, False, (seed, t0, t1))   # spheres only: exact
     assert np.array_equal(got, exact)
     assert np.array_equal(ids, ob.first_hit(scene, ocam, 72, 54)), seed
 
@@ -332,7 +332,7 @@ def test_random_world_importance_sampling_matches_oracle(seed, monkeypatch):
             finally:
                 c.close()
             assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, flags, set_min)
-            assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, flags, set_min)
+            assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, flags, set_min))
 
 
 def random_big_set_world(seed):
@@ -393,7 +393,7 @@ def test_random_big_set_world_matches_oracle(seed, monkeypatch):
         finally:
             c.close()
         assert st["rays"] == ost["rays"], (seed, set_min)
-        assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, set_min)
+        assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, set_min))
         assert np.array_equal(got, exact) and np.array_equal(ids, want_ids), (seed, set_min)
 
 
@@ -458,7 +458,7 @@ def check_flat_list_case(seed):
         c.close()
     what = (seed, W, H, p.sample_count, p.max_depth, p.sample_begin)
     assert st["rays"] == ost["rays"] == se["rays"] and st["samples"] == W * H * p.sample_count, what
-    assert np.array_equal(got, fixed.astype(np.float64) / FRAC), what
+    assert_sums_match(got, fixed.astype(np.float64) / FRAC, False, what)   # a book-1 list: exact
     assert np.array_equal(got, exact), what
     assert np.array_equal(ids, ob.first_hit(scene, ocam, W, H)), what
 
@@ -509,7 +509,7 @@ def test_random_world_at_other_scales(family, seed, scale, monkeypatch):
         finally:
             c.close()
         assert st["rays"] == ost["rays"], (seed, scale, set_min)
-        assert np.array_equal(got, fixed.astype(np.float64) / FRAC), (seed, scale, set_min)
+        assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, scale, set_min))
         assert np.array_equal(ids, ob.first_hit(scene, ocam, 60, 45)), (seed, scale, set_min)
 
 
@@ -547,4 +547,4 @@ def test_perlin_noise_beyond_the_int_range(scale):
     finally:
         c.close()
     assert st["rays"] == ost["rays"]
-    assert np.array_equal(got, fixed.astype(np.float64) / FRAC)
+    assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, None)
