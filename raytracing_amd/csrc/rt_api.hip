@@ -1249,6 +1249,7 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
         fill_camera(A.cam, cam);
         A.width = p->width;
         A.height = p->height;
+        A.wdiv = make_width_divider(p->width);
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;
@@ -1277,6 +1278,7 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
         fill_camera(A.cam, cam);
         A.width = p->width;
         A.height = p->height;
+        A.wdiv = make_width_divider(p->width);
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;

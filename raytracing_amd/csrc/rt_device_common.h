@@ -94,6 +94,11 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// n / width for n < 2^28 with the multiplier and shift of make_width_divider (rt_internal.h)
+__device__ __forceinline__ uint32_t div_by_width(uint32_t n, uint32_t mul, uint32_t shift) {
+    return (uint32_t)(((uint64_t)n * (uint64_t)mul) >> shift);
+}
+
 constexpr double ACCUM_SCALE = (double)(1ull << RT_ACCUM_FRAC_BITS);
 
 }  // namespace rtd

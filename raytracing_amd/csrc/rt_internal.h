@@ -112,10 +112,26 @@ struct CameraDev {
     double lens_radius, time0, time1;
 };
 
+// pixel -> (column, row) without an integer division per sample: n / width = (n * mul) >> shift, exact for n < 2^28
+// (mul = ceil(2^shift / width), shift = 28 + ceil(log2 width): the error term n e / (width 2^shift), e < width, stays
+// below 1 / width)
+struct WidthDivider {
+    uint32_t mul, shift;
+};
+inline WidthDivider make_width_divider(int32_t width) {
+    uint32_t l = 0;
+    while ((1u << l) < (uint32_t)width) ++l;
+    WidthDivider d;
+    d.shift = 28u + l;
+    d.mul = (uint32_t)((((uint64_t)1 << d.shift) + (uint64_t)width - 1u) / (uint64_t)width);
+    return d;
+}
+
 struct RenderArgs {
     SphereListDev scene;
     CameraDev cam;
     int32_t width, height;
+    WidthDivider wdiv;
     int32_t sample_begin, sample_count;
     int32_t max_depth;
     int32_t item_cap;       // longest run of samples of one pixel that forms a work item (see ItemPlan)
@@ -214,6 +230,7 @@ struct SceneRenderArgs {
     SceneDev scene;
     CameraDev cam;
     int32_t width, height;
+    WidthDivider wdiv;
     int32_t sample_begin, sample_count;
     int32_t max_depth;
     int32_t item_cap;

@@ -796,26 +796,18 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
     return (1 / pdf_val) * (spdf * attenuation);
 }
 
-__device__ __forceinline__ Ray primary_ray(const CameraDev& C, int W, int H, uint32_t pixel, uint32_t sample, uint32_t k0,
-                                           uint32_t k1, double& tm) {
-    const int i = (int)(pixel % (uint32_t)W);
-    const int j = H - 1 - (int)(pixel / (uint32_t)W);
-    Ray r;
-    camera_ray(C, W, H, i, j, pixel, sample, k0, k1, r.o, r.d);
-    tm = C.time0;
-    if (C.time0 != C.time1) {  // B2/camera.h:44; with equal times the draw would not change the value
-        const u32x4 w = philox4x32_10(pixel, sample, 0u, TRY_TIME, k0, k1);
-        tm = u_range(w.x, C.time0, C.time1);
-    }
-    return r;
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------- render kernel
 #ifndef RT_SCENE_MIN_WAVES
 #define RT_SCENE_MIN_WAVES 3
 #endif
+// Philox blocks of the rejection loops computed by the whole wave (philox_blocks_for_lanes)?  Measured on these
+// kernels, which wait on dependent loads rather than on vector issue: no gain (final scene -1 %, Cornell box +3 %).
+#ifndef RT_SCENE_WAVE_BLOCKS
+#define RT_SCENE_WAVE_BLOCKS 0
+#endif
+constexpr bool SCENE_WAVE_BLOCKS = RT_SCENE_WAVE_BLOCKS != 0;
 template <int F, int MIN_WAVES>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRenderArgs A) {
     __shared__ uint32_t s_stack[4][STACK_CAP * 64];
@@ -853,13 +845,18 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
 #endif
     for (;;) {
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
-        if (!active && w.has_item) {
-            r = primary_ray(cam, A.width, A.height, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, tm);
-            T = d3{1, 1, 1};
-            depth_left = A.max_depth;
-            bounce = 0;
-            active = true;
-            ++n_samples;
+        {   // the lanes that start a sample; their camera rays come from Philox blocks the whole wave computes
+            const bool start = !active && w.has_item;
+            const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
+            camera_ray_for_lanes<true, SCENE_WAVE_BLOCKS>(start, cam, A.width, A.height, (int)(w.pixel - row * (uint32_t)A.width), A.height - 1 - (int)row,
+                                       w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane, nullptr, r.o, r.d, tm);
+            if (start) {
+                T = d3{1, 1, 1};
+                depth_left = A.max_depth;
+                bounce = 0;
+                active = true;
+                ++n_samples;
+            }
         }
         const bool on = active;
         const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
@@ -869,11 +866,26 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         probe_t = clock64();  // trace() accounts for its own sections
 #endif
 
+        // the hit record and the material of the lanes that hit something; then, for all lanes together, the first Philox
+        // block of the segment's site (every material's first draw: sphere sampler, reflectance, light mixture) and the
+        // unit-sphere rejection loop
+        const bool hit = on && h.node >= 0;
+        constexpr bool importance = (F & F_IS) != 0;  // variants with F_IS only run with RT_RENDER_IMPORTANCE
+        Surface s{};
+        MaterialDev m{RT_MAT_DIFFUSE_LIGHT, -1, 0, 0, 0, 0};
+        if (hit) {
+            s = make_surface<F>(S, h, r, tm);
+            m = S.materials[s.mat];
+        }
+        const bool wants_sphere = hit && ((!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
+                                          (!importance && m.kind == RT_MAT_ISOTROPIC));
+        const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
+        const d3 rs = random_in_unit_sphere_for_lanes<SCENE_WAVE_BLOCKS>(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1, lane, nullptr);
         if (on) {
             ++n_rays;
             bool done = false;
             d3 L_end{0, 0, 0};
-            if (h.node < 0) {
+            if (!hit) {
                 if (S.sky_mode == RT_SKY_GRADIENT) {
                     const d3 unit_direction = unit_vector(r.d);
                     const double t = 0.5 * (unit_direction.y + 1.0);
@@ -883,16 +895,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                 }
                 done = true;
             } else {
-                Surface s = make_surface<F>(S, h, r, tm);
-                const MaterialDev m = S.materials[s.mat];
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
-                const bool importance = (F & F_IS) != 0;  // variants with F_IS only run with RT_RENDER_IMPORTANCE
-                const bool wants_sphere = (!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
-                                          (!importance && m.kind == RT_MAT_ISOTROPIC);
-                // Philox block 0 of the site is every material's first draw (sphere sampler, reflectance, light mixture)
-                const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
-                const d3 rs = random_in_unit_sphere(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1);
                 // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code)
                 const bool wants_texture = m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
                                            (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face));

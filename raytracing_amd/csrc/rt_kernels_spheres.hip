@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, A.pixel_pass != 0);
     __shared__ AccumCache s_acc[4];
+    constexpr bool WAVE_BLOCKS = !TIMED && (RT_COOP_SHADE != 0);  // Philox blocks of the rejection loops computed wave-wide
     accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
 
     // per-lane path state
@@ -102,22 +103,27 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     for (;;) {
         // ---- refill: finish items, take new ones, start the next sample
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
-        if (!active && w.has_item) {
-            const int i = (int)(w.pixel % (uint32_t)A.width);
-            const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);  // row 0 = top = j = H-1
-            camera_ray(cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, o, d);
-            if constexpr (TIMED) {
-                tm = cam.time0;
-                if (cam.time0 != cam.time1) {  // B2/camera.h:44; with equal times the draw would not change the value
-                    const u32x4 tw = philox4x32_10(w.pixel, (uint32_t)w.s_cur, 0u, TRY_TIME, A.key0, A.key1);
-                    tm = u_range(tw.x, cam.time0, cam.time1);
-                }
+        {   // the lanes that start a sample
+            const bool start = !active && w.has_item;
+            if constexpr (WAVE_BLOCKS) {
+                const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
+                const int i = (int)(w.pixel - row * (uint32_t)A.width);
+                const int j = A.height - 1 - (int)row;  // row 0 = top = j = H-1
+                camera_ray_for_lanes<TIMED, RT_COOP_CAMERA != 0>(start, cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0,
+                                                                 A.key1, lane, nullptr, o, d, tm);
+            } else if (start) {  // (the book-2 variant is at its register limit: every lane computes its own blocks, in the branch)
+                const int i = (int)(w.pixel % (uint32_t)A.width);
+                const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);
+                camera_ray_for_lanes<TIMED, false>(true, cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane,
+                                                   nullptr, o, d, tm);
             }
-            T = d3{1, 1, 1};
-            depth_left = A.max_depth;
-            bounce = 0;
-            active = true;
-            ++n_samples;
+            if (start) {
+                T = d3{1, 1, 1};
+                depth_left = A.max_depth;
+                bounce = 0;
+                active = true;
+                ++n_samples;
+            }
         }
         // ---- closest hit (all lanes together)
         const bool on = active;
@@ -137,19 +143,37 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
         const SetHit h = closest_hit<TIMED>(S.set, o, d, tm, __builtin_inf(), on, A.exact_only != 0, list, rows, lane, n_overflow, pc);
 
         // ---- shade
+        const bool hit = on && h.id >= 0;
+        const uint32_t site = 1u + bounce;
+        // Every material's first draw is block 0 of the segment's site.  Book-1 kernel: the block and the unit-sphere
+        // rejection loop of lambertian and metal run at wave level, the loop's further blocks computed by the whole wave
+        // for the lanes still in it (only two words per lane stay live across it).
+        int mat = 0;
+        u32x4 block0{0, 0, 0, 0};
+        d3 rs{0, 0, 0};
+        if constexpr (WAVE_BLOCKS) {
+            int mat_kind = RT_MAT_DIELECTRIC;
+            if (hit) {
+                mat = S.material_of[h.id];
+                mat_kind = S.materials[mat].kind;
+            }
+            const bool wants_sphere = hit && (mat_kind == RT_MAT_LAMBERTIAN || mat_kind == RT_MAT_METAL);
+            block0 = philox4x32_10(w.pixel, (uint32_t)w.s_cur, site, 0u, A.key0, A.key1);
+            rs = random_in_unit_sphere_for_lanes(wants_sphere, block0, w.pixel, (uint32_t)w.s_cur, site, A.key0, A.key1, lane, nullptr);
+        }
+#ifdef RT_PROBE_SPLIT
+        pc.mark(SEC_SCREEN_SPARSE);
+#endif
         if (on) {
             ++n_rays;
-            const uint32_t sample = (uint32_t)w.s_cur;
-            const uint32_t pixel = w.pixel;
-            const uint32_t site = 1u + bounce;
             bool done = false;
             d3 L_end{0, 0, 0};
-            const bool hit = h.id >= 0;
             SphereExact e{0, 0, 0, 1};
             MaterialDev m{RT_MAT_LAMBERTIAN, -1, 0, 0, 0, 0};
             if (hit) {
                 e = S.set.exact[h.id];
-                m = S.materials[S.material_of[h.id]];
+                if constexpr (!WAVE_BLOCKS) mat = S.material_of[h.id];
+                m = S.materials[mat];
             }
             // unit_vector(r.direction()) is wanted by the sky, by metal and by dielectric: one copy of the square
             // root and division for all of them instead of one per divergent branch
@@ -174,9 +198,11 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     if (m.tex >= 0) attenuation = sphere_world_texture(S, m.tex, p);
                 }
                 d3 nd{0, 0, 0};
-                const bool wants_sphere = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL;
-                const u32x4 block0 = philox4x32_10(pixel, sample, site, 0u, A.key0, A.key1);  // every material's first draw
-                const d3 rs = random_in_unit_sphere(wants_sphere, block0, pixel, sample, site, A.key0, A.key1);
+                if constexpr (!WAVE_BLOCKS) {
+                    block0 = philox4x32_10(w.pixel, (uint32_t)w.s_cur, site, 0u, A.key0, A.key1);
+                    rs = random_in_unit_sphere(m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL, block0, w.pixel, (uint32_t)w.s_cur, site,
+                                               A.key0, A.key1);
+                }
                 if (m.kind == RT_MAT_LAMBERTIAN) {  // B1/material.h:19-30
                     nd = normal + unit_vector(rs);
                     const double s = 1e-8;

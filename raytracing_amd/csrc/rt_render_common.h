@@ -64,6 +64,158 @@ __device__ __forceinline__ d3 random_in_unit_sphere(bool need, u32x4 block0, uin
     return p;
 }
 
+// ---------------------------------------------------------------- Philox blocks computed by the wave for its lanes
+//
+// A rejection loop runs as long as its unluckiest lane, and in every round the whole wave issues the ~60 vector
+// instructions of a Philox block for the few lanes still in the loop.  Here the lanes that want blocks are served by
+// ALL lanes instead: NB lanes per wanting lane compute its next NB blocks side by side, in one evaluation, and the
+// words travel back by lane permutation.  (The rounds that a loop of one block per round would take are mostly known
+// to be needed: after a failed first attempt of the unit-sphere sampler, 48 % of the lanes need the second block too.)
+// Same blocks, same words, same draws as computing them one by one: results do not change.
+//
+// want: this lane wants blocks first .. first+NB-1 of counter (c0, c1, c2, .); alt_last != 0 replaces the index of the
+// last one.  All 64 lanes must call it.  When more than 63/NB lanes want blocks, every lane computes its own (NB
+// evaluations).
+__device__ __forceinline__ uint32_t lane_pull(int src_lane, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ uint32_t lane_push(int dst_lane, uint32_t v) {  // what was pushed to this lane (0 if nothing)
+    return (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)v);
+}
+template <int NB>
+__device__ __forceinline__ void philox_blocks_for_lanes(bool want, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t first,
+                                                        uint32_t alt_last, uint32_t k0, uint32_t k1, int lane, uint8_t* /*owners*/,
+                                                        u32x4 (&out)[NB]) {
+    const uint64_t m = ballot(want);
+    const int n = __popcll(m);
+    if (n * NB <= 63) {
+        // The wanting lane of rank r pushes its counter to lanes NB r .. NB r + NB - 1 (one forward permutation per word
+        // and destination; the other lanes push to lane 63, which serves nobody), those lanes compute one block each, and
+        // the owner pulls the words back: two permutation latencies around one Philox evaluation.
+        const int base = (int)rank_below(m) * NB;
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int dst = want ? base + j : 63;
+            const uint32_t idx = (j == NB - 1 && alt_last != 0u) ? alt_last : first + (uint32_t)j;
+            const uint32_t r0 = lane_push(dst, c0), r1 = lane_push(dst, c1), r2 = lane_push(dst, c2), r3 = lane_push(dst, idx);
+            const bool mine = lane - (lane / NB) * NB == j;  // this lane is destination j of its slot
+            b0 = mine ? r0 : b0;
+            b1 = mine ? r1 : b1;
+            b2 = mine ? r2 : b2;
+            b3 = mine ? r3 : b3;
+        }
+        const u32x4 r = philox4x32_10(b0, b1, b2, b3, k0, k1);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            out[j] = u32x4{lane_pull(base + j, r.x), lane_pull(base + j, r.y), lane_pull(base + j, r.z), lane_pull(base + j, r.w)};
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            out[j] = philox4x32_10(c0, c1, c2, (j == NB - 1 && alt_last != 0u) ? alt_last : first + (uint32_t)j, k0, k1);
+    }
+}
+
+// camera::get_ray (B1/camera.h:34-39, B2/camera.h:38-45) for the lanes with `start` set, the Philox blocks coming from
+// philox_blocks_for_lanes: blocks 0 and 1 (jitter, lens attempts 0 to 2) in one evaluation -- blocks 0 and TRY_TIME when
+// the camera has a shutter interval -- and two more per further evaluation for the lanes still rejecting lens points.
+// Same draws as camera_ray.  All 64 lanes must call it.
+#ifndef RT_COOP_CAMERA
+#define RT_COOP_CAMERA 1
+#endif
+#ifndef RT_COOP_SHADE
+#define RT_COOP_SHADE 1
+#endif
+template <bool TIMED, bool COOP = (RT_COOP_CAMERA != 0)>
+__device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev& C, int W, int H, int i, int j, uint32_t pixel,
+                                                     uint32_t sample, uint32_t k0, uint32_t k1, int lane, uint8_t* owners, d3& o,
+                                                     d3& d, double& tm) {
+    if constexpr (!COOP) {
+        if (start) {
+            camera_ray(C, W, H, i, j, pixel, sample, k0, k1, o, d);
+            if constexpr (TIMED) {
+                tm = C.time0;
+                if (C.time0 != C.time1) tm = u_range(philox4x32_10(pixel, sample, 0u, TRY_TIME, k0, k1).x, C.time0, C.time1);
+            }
+        }
+        return;
+    }
+    u32x4 b[2];
+    philox_blocks_for_lanes<2>(start, pixel, sample, 0u, 0u, TIMED ? TRY_TIME : 0u, k0, k1, lane, owners, b);
+    const double s = (i + u01(b[0].x)) / (W - 1);  // B1/RayTracing.cpp:120-121
+    const double t = (j + u01(b[0].y)) / (H - 1);
+    double px = u_range(b[0].z, -1, 1), py = u_range(b[0].w, -1, 1);
+    bool need = start && px * px + py * py + 0.0 * 0.0 >= 1;  // random_in_unit_disk
+    auto attempt = [&](uint32_t x, uint32_t y) {
+        if (need) {
+            px = u_range(x, -1, 1);
+            py = u_range(y, -1, 1);
+            need = px * px + py * py + 0.0 * 0.0 >= 1;
+        }
+    };
+    uint32_t next = 2u;  // next block of lens attempts to fetch
+    if constexpr (TIMED) {
+        if (start) tm = C.time0 != C.time1 ? u_range(b[1].x, C.time0, C.time1) : C.time0;  // B2/camera.h:44
+        next = 1u;
+    } else {
+        attempt(b[1].x, b[1].y);
+        attempt(b[1].z, b[1].w);
+    }
+    while (ballot(need) != 0ull) {
+        philox_blocks_for_lanes<2>(need, pixel, sample, 0u, next, 0u, k0, k1, lane, owners, b);
+        attempt(b[0].x, b[0].y);
+        attempt(b[0].z, b[0].w);
+        attempt(b[1].x, b[1].y);
+        attempt(b[1].z, b[1].w);
+        next += 2u;
+    }
+    if (start) {
+        const double rdx = C.lens_radius * px, rdy = C.lens_radius * py;
+        const d3 cu{C.u[0], C.u[1], C.u[2]}, cv{C.v[0], C.v[1], C.v[2]};
+        const d3 offset = rdx * cu + rdy * cv;
+        const d3 origin{C.origin[0], C.origin[1], C.origin[2]};
+        const d3 llc{C.llc[0], C.llc[1], C.llc[2]};
+        const d3 hor{C.horizontal[0], C.horizontal[1], C.horizontal[2]};
+        const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
+        o = origin + offset;
+        d = llc + s * hor + t * ver - origin - offset;
+    }
+}
+
+// random_in_unit_sphere (B1/vec3.h:114-120) for the lanes with need == true, the blocks beyond block0 coming from
+// philox_blocks_for_lanes: blocks 1 and 2 (attempts 1 to 3) in one evaluation, then three per evaluation (four attempts).
+// Same draws as random_in_unit_sphere below.  All 64 lanes must call it.
+template <bool COOP = (RT_COOP_SHADE != 0)>
+__device__ __forceinline__ d3 random_in_unit_sphere_for_lanes(bool need, u32x4 block0, uint32_t pixel, uint32_t sample,
+                                                              uint32_t site, uint32_t k0, uint32_t k1, int lane, uint8_t* owners) {
+    if constexpr (!COOP) return random_in_unit_sphere(need, block0, pixel, sample, site, k0, k1);
+    d3 p{0, 0, 0};
+    auto attempt = [&](uint32_t x, uint32_t y, uint32_t z) {
+        if (need) {
+            p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
+            if (!(len2(p) >= 1)) need = false;
+        }
+    };
+    attempt(block0.x, block0.y, block0.z);
+    if (ballot(need) == 0ull) return p;
+    {
+        u32x4 b[2];
+        philox_blocks_for_lanes<2>(need, pixel, sample, site, 1u, 0u, k0, k1, lane, owners, b);
+        attempt(b[0].x, b[0].y, b[0].z);
+        if (ballot(need) != 0ull) attempt(b[1].x, b[1].y, b[1].z);
+        if (ballot(need) != 0ull) attempt(block0.w, b[0].w, b[1].w);
+    }
+    for (uint32_t g = 1; ballot(need) != 0ull; ++g) {
+        u32x4 b[3];
+        philox_blocks_for_lanes<3>(need, pixel, sample, site, 3u * g, 0u, k0, k1, lane, owners, b);
+        attempt(b[0].x, b[0].y, b[0].z);
+        if (ballot(need) != 0ull) attempt(b[1].x, b[1].y, b[1].z);
+        if (ballot(need) != 0ull) attempt(b[2].x, b[2].y, b[2].z);
+        if (ballot(need) != 0ull) attempt(b[0].w, b[1].w, b[2].w);
+    }
+    return p;
+}
+
 __device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  // B1/material.h:83-88
     double r0 = (1 - ref_idx) / (1 + ref_idx);
     r0 = r0 * r0;
