@@ -1214,7 +1214,8 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
     bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
     const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, pixel_pass);
     const int64_t items = (int64_t)item_count(plan, npix);
-    if (items > 0xFFFF0000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
+    // (room above the last item for the one batch every wave still adds to the queue head when it finds it dry)
+    if (items > 0xFF000000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
     const bool importance = (p->flags & RT_RENDER_IMPORTANCE) != 0;
     if (importance && (spheres || !ctx->graph_can_importance))
         return fail(ctx, RT_ERR_UNSUPPORTED_SCENE,

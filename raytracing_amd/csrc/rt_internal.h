@@ -135,7 +135,7 @@ struct RenderArgs {
     int32_t sample_begin, sample_count;
     int32_t max_depth;
     int32_t item_cap;       // longest run of samples of one pixel that forms a work item (see ItemPlan)
-    int32_t pixel_pass;     // 1: full runs are numbered pixel by pixel and summed in the accumulation cache
+    int32_t pixel_pass;     // 1: runs are numbered pixel by pixel and summed in the accumulation cache (ItemPlan)
     uint32_t n_items;       // number of work items
     uint32_t key0, key1;    // Philox key
     int32_t exact_only;     // 1: skip the float screen, test every sphere in double (validation)

@@ -837,7 +837,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     double tm = 0.0;
     LaneWork w{};
     WaveWork wq{};
-    const WorkQueues Q{A.item_counter, A.n_items, A.accum, nullptr};  // no accumulation cache: these kernels are short of registers
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum, nullptr, plan.batch, false};  // no accumulation cache: these kernels are short of registers
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0;
 
 #ifdef RT_SCENE_PROBE

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     double tm = 0.0;  // ray::time(), the same for every segment of a path (TIMED only)
     LaneWork w{};
     WaveWork wq{};
-    const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6]};
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6], plan.batch, plan.exclusive};
     uint32_t n_samples = 0, n_rays = 0, n_bad = 0, n_overflow = 0;
 #ifdef RT_TAIL_PROBE
     const uint64_t pr_t0 = wall_clock64();

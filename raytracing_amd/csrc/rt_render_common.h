@@ -247,39 +247,72 @@ __device__ __forceinline__ bool checker_sines_negative(d3 p) {
 __device__ __forceinline__ void atomic_add_i64(int64_t* p, int64_t v) {
     __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same for a word that only this wave adds to during the launch: a plain load, add and store.  An agent-scope
+// atomic has to be coherent across the eight XCDs, whose L2 caches are not: it is carried out at the memory side, one
+// 64-byte request each (measured: WRITE_SIZE = 64 B x atomics), and a workgroup-scope atomic still costs most of that.
+// Plain stores stay in this XCD's L2 as dirty bytes and reach memory when the line is evicted or the kernel ends;
+// neighbouring words of the line that other waves own are written with their own byte masks.  Two additions to the
+// same word by this wave (a pixel that lost its cache slot and claimed one again) are ordered by the wavefront fences
+// of lds_wave_sync between them.
+__device__ __forceinline__ void add_i64_own(int64_t* p, int64_t v) { *p += v; }
 
-
-// Work items.  The samples [0, N) of a pixel are cut into `levels` runs: K runs of `cap` samples, then the
-// remaining R = N - K*cap (cap <= R < 2*cap when N >= cap) halved repeatedly: R - R/2, R/2 - R/4, ..., 1.
-// Items are numbered in two passes.  First the K full runs, pixel by pixel (all K runs of pixel 0, then of pixel 1,
-// ...): the 64 items of a batch belong to one or a few neighbouring pixels, so the lanes of a wave trace similar
-// rays and their sums meet in the wave's accumulation cache (below) instead of in memory.  Then the halved
-// remainders, run by run over the whole frame (every pixel's largest remainder first, one-sample runs last): the
-// queue ends in fine grains spread over all pixels, whatever single pixels cost.
+// Work items.  The samples [0, N) of a pixel are cut into runs ("levels"), one work item each.
+//
+// Frame-by-frame plan (pixel_pass = false): K runs of `cap` samples, then the remaining R = N - K*cap
+// (cap <= R < 2*cap when N >= cap) halved repeatedly: R - R/2, R/2 - R/4, ..., 1.  Items are numbered run by run over
+// the whole frame (one-sample runs last), so that the queue ends in fine grains spread over all pixels, whatever single
+// pixels cost.  Every item adds its sums to memory itself (three 64-bit atomics).
+//
+// Pixel-by-pixel plan (pixel_pass = true): K runs of `cap` samples and one run of the remaining R, numbered pixel by
+// pixel (all runs of pixel 0, then of pixel 1, ...).  A wave takes whole pixels from the queue (batches are multiples
+// of the runs per pixel while they fit 64 lanes), its lanes trace similar rays, and the sums of a pixel's runs meet in
+// the wave's accumulation cache (below) and reach memory once per pixel instead of once per run.  (Ending this queue in
+// fine grains as well -- one-sample items, or halved runs of every n-th pixel, after the long runs -- was measured and
+// changes nothing: the waves balance their own ends, see refill_work.)
 struct ItemPlan {
     int32_t cap, K, R, levels;
     uint32_t npix;
-    uint32_t bulk_items;  // npix * K
+    uint32_t bulk_items;  // pixel-by-pixel plan: npix * levels (every item); else 0
+    uint32_t batch;       // items a wave takes from the queue at a time, at most 64
+    bool exclusive;       // every item of a pixel goes to the same wave (whole pixels per batch)
 };
-// pixel_pass = false numbers every run frame by frame (no pixel-by-pixel pass, no use for the cache).
 __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap, uint32_t npix, bool pixel_pass) {
     ItemPlan p;
     p.cap = cap < 1 ? 1 : cap;
     p.K = n_samples / p.cap - 1;
     if (p.K < 0) p.K = 0;
     p.R = n_samples - p.K * p.cap;
-    int bits = 0;
-    for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
-    p.levels = p.K + bits;
     p.npix = npix;
-    p.bulk_items = (pixel_pass && p.K >= 2) ? npix * (uint32_t)p.K : 0u;
+    if (pixel_pass) {
+        p.levels = p.K + (p.R > 0 ? 1 : 0);
+        p.bulk_items = npix * (uint32_t)p.levels;
+        p.exclusive = p.levels >= 1 && p.levels <= 64;
+        p.batch = p.exclusive ? (uint32_t)((64 / p.levels) * p.levels) : 64u;
+    } else {
+        int bits = 0;
+        for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
+        p.levels = p.K + bits;
+        p.bulk_items = 0u;
+        p.batch = 64u;
+        p.exclusive = false;
+    }
     return p;
 }
 __host__ __device__ inline uint64_t item_count(const ItemPlan& p, uint32_t npix) {
     return (uint64_t)npix * (uint64_t)p.levels;
 }
-// samples [first, first + count) of run `level`, relative to the first sample of the call
-__device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& first, int& count) {
+// item number -> pixel and samples [first, first + count), relative to the first sample of the call
+__device__ __forceinline__ void item_lookup(const ItemPlan& p, uint32_t item, uint32_t& pixel, int& first, int& count) {
+    if (p.bulk_items != 0u) {
+        pixel = item / (uint32_t)p.levels;
+        const int level = (int)(item - pixel * (uint32_t)p.levels);
+        first = level * p.cap;
+        count = level < p.K ? p.cap : p.R;
+        return;
+    }
+    const uint32_t l = item / p.npix;
+    pixel = item - l * p.npix;
+    const int level = (int)l;
     if (level < p.K) {
         first = level * p.cap;
         count = p.cap;
@@ -288,20 +321,6 @@ __device__ __forceinline__ void item_run(const ItemPlan& p, int level, int& firs
         first = p.K * p.cap + p.R - (p.R >> g);
         count = (p.R >> g) - (p.R >> (g + 1));
     }
-}
-// item number -> pixel and samples [first, first + count)
-__device__ __forceinline__ void item_lookup(const ItemPlan& p, uint32_t item, uint32_t& pixel, int& first, int& count) {
-    int level;
-    if (item < p.bulk_items) {
-        pixel = item / (uint32_t)p.K;
-        level = (int)(item - pixel * (uint32_t)p.K);
-    } else {
-        const uint32_t t = item - p.bulk_items;
-        const uint32_t l = t / p.npix;
-        pixel = t - l * p.npix;
-        level = (p.bulk_items != 0u ? p.K : 0) + (int)l;
-    }
-    item_run(p, level, first, count);
 }
 
 // Accumulation cache of one wave (in LDS): fixed-point sums of the pixels the wave is working on.  A finished
@@ -314,6 +333,10 @@ struct AccumCache {
     int64_t sum[ACC_SLOTS][3];
     uint32_t tag[ACC_SLOTS];
 };
+// Slot of a pixel: a multiplicative hash, not the low bits -- the pixels a wave works on in a row are about as many
+// pixels apart as there are waves (a power of two), and would all claim the same slot.
+__device__ __forceinline__ int acc_slot_of(uint32_t pixel) { return (int)((pixel * 0x9E3779B1u) >> 28); }
+static_assert(ACC_SLOTS == 16, "acc_slot_of keeps the top four bits of the hash");
 
 // ---------------------------------------------------------------- work source of a persistent wave
 //
@@ -329,6 +352,8 @@ struct WorkQueues {
     int64_t* accum;
     AccumCache* cache;  // this wave's accumulation cache (LDS), set up with accum_cache_init; nullptr: none, and the
                         // plan must have been made without the pixel-by-pixel pass
+    uint32_t batch;     // items a wave takes from the queue at a time (ItemPlan::batch)
+    bool exclusive;     // ItemPlan::exclusive: a pixel's sums reach memory from one wave only, through its cache
 };
 
 __device__ __forceinline__ void lds_wave_sync() {
@@ -344,18 +369,35 @@ __device__ __forceinline__ void accum_cache_init(AccumCache* c, int lane) {
     lds_wave_sync();
 }
 __device__ __forceinline__ void accum_slot_to_memory(const WorkQueues& Q, int slot, uint32_t pixel) {
-    atomic_add_i64(Q.accum + 3ull * pixel + 0, Q.cache->sum[slot][0]);
-    atomic_add_i64(Q.accum + 3ull * pixel + 1, Q.cache->sum[slot][1]);
-    atomic_add_i64(Q.accum + 3ull * pixel + 2, Q.cache->sum[slot][2]);
+    if (Q.exclusive) {
+        add_i64_own(Q.accum + 3ull * pixel + 0, Q.cache->sum[slot][0]);
+        add_i64_own(Q.accum + 3ull * pixel + 1, Q.cache->sum[slot][1]);
+        add_i64_own(Q.accum + 3ull * pixel + 2, Q.cache->sum[slot][2]);
+    } else {
+        atomic_add_i64(Q.accum + 3ull * pixel + 0, Q.cache->sum[slot][0]);
+        atomic_add_i64(Q.accum + 3ull * pixel + 1, Q.cache->sum[slot][1]);
+        atomic_add_i64(Q.accum + 3ull * pixel + 2, Q.cache->sum[slot][2]);
+    }
 }
 // Adds the sums of the lanes with `fl` set (their finished items) to the cache.  All 64 lanes must call it.
+// A lane whose pixel already owns its slot -- every item of a pixel but the first -- adds in one step; only the lanes
+// that have to claim a slot (writing another pixel's sums back) go through the loop, one trip per distinct pixel.
 __device__ __forceinline__ void accum_cache_add(const WorkQueues& Q, int lane, bool fl, uint32_t pixel, int64_t fx, int64_t fy,
                                                 int64_t fz) {
-    uint64_t todo = ballot(fl);
-    while (todo != 0ull) {  // one trip per distinct pixel among the finishing lanes
+    const int my_slot = acc_slot_of(pixel);
+    const bool fast = fl && Q.cache->tag[my_slot] == pixel;
+    if (fast) {
+        __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[my_slot][0], (unsigned long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[my_slot][1], (unsigned long long)fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[my_slot][2], (unsigned long long)fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    uint64_t todo = ballot(fl && !fast);
+    if (todo == 0ull) return;
+    lds_wave_sync();  // the additions above come before any slot changes hands
+    while (todo != 0ull) {  // one trip per distinct pixel among the remaining lanes
         const int src = __builtin_ctzll(todo);
         const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pixel, src);
-        const int slot = (int)(p & (uint32_t)(ACC_SLOTS - 1));
+        const int slot = acc_slot_of(p);
         const uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)Q.cache->tag[slot]);
         if (tag != p) {  // wave-uniform: the slot holds another pixel (or nothing): write it back, take the slot
             if (lane == src) {
@@ -365,7 +407,7 @@ __device__ __forceinline__ void accum_cache_add(const WorkQueues& Q, int lane, b
             }
             lds_wave_sync();
         }
-        const bool mine = fl && pixel == p;
+        const bool mine = fl && !fast && pixel == p;
         if (mine) {
             __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[slot][0], (unsigned long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add((unsigned long long*)&Q.cache->sum[slot][1], (unsigned long long)fy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -402,8 +444,8 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
                                             int lane, bool active, LaneWork& w, WaveWork& q) {
     {
         const bool finished = !active && w.has_item && w.s_cur == w.s_end;
-        // Items of the pixel-by-pixel pass meet their pixel's other items in the cache; the few remainder items and
-        // handed-over samples of a pixel are far apart in time and go to memory directly.
+        // Items of the pixel-by-pixel plan meet their pixel's other items in the cache; items of the frame-by-frame
+        // plan (and samples handed over when a pixel's items are spread over several waves) go to memory directly.
         if (Q.cache != nullptr && ballot(finished && w.cached) != 0ull)
             accum_cache_add(Q, lane, finished && w.cached, w.pixel, w.fx, w.fy, w.fz);
         if (finished && !w.cached) {
@@ -417,14 +459,15 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
     while (!q.dry && ballot(need) != 0ull) {
         if (q.batch_next == q.batch_end) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(Q.counter, 64u);
+            const uint32_t take = Q.batch;
+            if (lane == 0) base = atomicAdd(Q.counter, take);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (base >= Q.n_items) {
                 q.dry = true;
                 break;
             }
             q.batch_next = base;
-            q.batch_end = min(base + 64u, Q.n_items);
+            q.batch_end = min(base + take, Q.n_items);
         }
         const uint64_t m = ballot(need);
         const uint32_t rank = rank_below(m);
@@ -453,7 +496,7 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
         const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)w.pixel, g);
         const int32_t smp = __builtin_amdgcn_readlane(w.s_end, g);
         if (lane == t) {
-            w.cached = false;
+            w.cached = Q.exclusive;  // the giver's pixel is this wave's own: its cache takes the sample's sums as well
             w.pixel = px;
             w.s_cur = smp;
             w.s_end = smp + 1;

@@ -323,3 +323,21 @@ def test_spheres_beyond_the_float_screens_range_are_tested_in_double(ctx):
     assert st["rays"] == ost["rays"]
     assert np.array_equal(got, fixed.astype(np.float64) / 2.0 ** abi.RT_ACCUM_FRAC_BITS)
     assert np.array_equal(ctx.first_hit(cam, 120, 68), ob.first_hit(scene, ob.camera(*CAM_C1), 120, 68))
+
+
+def test_calls_that_add_to_one_device_buffer(scene_c2):
+    """rt_render_device ADDS: two calls on one buffer, each long enough for the pixel-by-pixel plan (whose waves add a
+    pixel's sums to memory with plain loads and stores, the pixel being theirs alone), give the frame of one call."""
+    import torch
+    cam = lib.camera(*CAM_C2)
+    W, H = 50, 34
+    with lib.Context(0) as c:
+        c.upload(scene_c2)
+        buf = torch.zeros((H, W, 3), dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        c.render_device(cam, abi.render_params(W, H, 130, 50, seed=4), buf.data_ptr())
+        c.render_device(cam, abi.render_params(W, H, 120, 50, seed=4, sample_begin=130), buf.data_ptr())
+        c.render_device(cam, abi.render_params(W, H, 7, 50, seed=4, sample_begin=250), buf.data_ptr())   # frame-by-frame plan
+        got = c.read_sums(buf.data_ptr(), W, H)
+        want, _ = c.render(cam, abi.render_params(W, H, 257, 50, seed=4))
+    assert np.array_equal(got, want)
