@@ -645,9 +645,18 @@ static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::ve
             bp.hw[k][i & 1] = hw_f;
         }
     }
+    std::vector<BoxExact> exact((size_t)std::max(1, n));
+    for (int i = 0; i < n; ++i) {
+        const rt_node& nd = sc->nodes[prims[(size_t)i]];
+        BoxExact e{};
+        for (int k = 0; k < 6; ++k) e.corner[k] = nd.p[k];
+        e.first_side = sc->children[nd.child0];  // a box of the reference's form: its sides are numbered consecutively
+        exact[(size_t)i] = e;
+    }
     B = BoxSetDev{};
     int rc;
     if ((rc = to_device(ctx, screen, &B.screen)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, exact, &B.exact)) != RT_OK) return rc;
     B.n = n;
     B.cover = (float)cover;
     if ((double)B.cover > cover) B.cover = std::nextafterf(B.cover, 0.0f);  // never claim more than the margin covers

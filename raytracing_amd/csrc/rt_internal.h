@@ -85,10 +85,18 @@ struct BoxClustersDev {
     const BoxPair* pairs;     // CLUSTER_SIZE / 2 per cluster; a padding slot has a negative half-width: never a candidate
     const uint16_t* members;  // CLUSTER_SIZE per cluster: index in the set, NO_MEMBER for padding
 };
+// What the double-precision test of box j needs, in one 64-byte record (a candidate's index leads straight to it:
+// no walk from the set's node list to the node).
+struct BoxExact {
+    double corner[6];    // box_min, box_max (B2/box.h:28-30)
+    int32_t first_side;  // node id of the first of the six sides
+    int32_t pad[3];
+};
 struct BoxSetDev {
     int32_t n;
     float cover;            // the margin holds for rays whose origin coordinates are at most this in magnitude
     const BoxPair* screen;  // padded to whole groups of SCREEN_GROUP boxes
+    const BoxExact* exact;  // per box, in set order
     BoxClustersDev clusters;
 };
 // The leaves of a DEV_NODE_LEAF_SET node: spheres, then boxes.

@@ -423,10 +423,11 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                             ProbeClock clk;
                             const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, overflowed, clk,
                                                                [&](int j, SetHit& best) {
+                                // (the set's own copies of centre and radius: no walk from the node list to the node)
+                                const SphereExact se = set.spheres.exact[j];
                                 const int id = S.set_nodes[first_slot + j];
-                                const SceneNode sn = S.nodes[id];
                                 double t;
-                                if (hit_sphere(d3{sn.p[0], sn.p[1], sn.p[2]}, sn.p[3], loc, loc_a, T_MIN, best.t, t)) {
+                                if (hit_sphere(d3{se.cx, se.cy, se.cz}, se.radius, loc, loc_a, T_MIN, best.t, t)) {
                                     best.t = t;
                                     best.id = j;
                                     best.aux = id;
@@ -443,11 +444,11 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                             if (set.boxes.n > 0) {
                                 const int first_box = first_slot + set.spheres.n;
                                 const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, [&](int j, SetHit& best) {
-                                    const SceneNode bn = S.nodes[S.set_nodes[first_box + j]];
-                                    const int side = hit_box6(bn.p, loc, T_MIN, best.t);
+                                    const BoxExact be = set.boxes.exact[j];
+                                    const int side = hit_box6(be.corner, loc, T_MIN, best.t);
                                     if (side >= 0) {
                                         best.id = j;
-                                        best.aux = bn.c + side;
+                                        best.aux = be.first_side + side;
                                     }
                                 });
                                 // A box side hit at exactly the sphere's t: bvh_node::hit accepts an equal root
