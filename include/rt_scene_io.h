@@ -60,6 +60,12 @@ static inline void rt_scene_file_free(rt_scene_file* f) {
     memset(f, 0, sizeof(*f));
 }
 
+/* fwrite of n elements; an empty array may be a null pointer, which fwrite must not be handed */
+static inline int rt_scene_file_write_array_(FILE* fp, const void* a, size_t elem, int32_t n) {
+    if (n < 0 || (n > 0 && !a)) return 0;
+    return n == 0 || fwrite(a, elem, (size_t)n, fp) == (size_t)n;
+}
+
 static inline int rt_scene_file_write(const char* path, const rt_scene_desc* s) {
     FILE* fp = fopen(path, "wb");
     if (!fp) return RT_ERR_INVALID_ARGUMENT;
@@ -68,11 +74,11 @@ static inline int rt_scene_file_write(const char* path, const rt_scene_desc* s) 
     int ok = fwrite("RTSCENE1", 1, 8, fp) == 8;
     ok = ok && fwrite(head, sizeof(int32_t), 8, fp) == 8;
     ok = ok && fwrite(s->background, sizeof(double), 3, fp) == 3;
-    ok = ok && fwrite(s->nodes, sizeof(rt_node), (size_t)s->n_nodes, fp) == (size_t)s->n_nodes;
-    ok = ok && fwrite(s->children, sizeof(int32_t), (size_t)s->n_children, fp) == (size_t)s->n_children;
-    ok = ok && fwrite(s->materials, sizeof(rt_material), (size_t)s->n_materials, fp) == (size_t)s->n_materials;
-    ok = ok && fwrite(s->textures, sizeof(rt_texture), (size_t)s->n_textures, fp) == (size_t)s->n_textures;
-    ok = ok && fwrite(s->perlins, sizeof(rt_perlin), (size_t)s->n_perlins, fp) == (size_t)s->n_perlins;
+    ok = ok && rt_scene_file_write_array_(fp, s->nodes, sizeof(rt_node), s->n_nodes);
+    ok = ok && rt_scene_file_write_array_(fp, s->children, sizeof(int32_t), s->n_children);
+    ok = ok && rt_scene_file_write_array_(fp, s->materials, sizeof(rt_material), s->n_materials);
+    ok = ok && rt_scene_file_write_array_(fp, s->textures, sizeof(rt_texture), s->n_textures);
+    ok = ok && rt_scene_file_write_array_(fp, s->perlins, sizeof(rt_perlin), s->n_perlins);
     for (int i = 0; ok && i < s->n_images; ++i) {
         int32_t wh[2] = {s->images[i].width, s->images[i].height};
         size_t n = (size_t)3 * (size_t)wh[0] * (size_t)wh[1];
