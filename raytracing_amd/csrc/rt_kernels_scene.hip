@@ -424,6 +424,9 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                             const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, overflowed, clk,
                                                                [&](int j, SetHit& best) {
                                 // (the set's own copies of centre and radius: no walk from the node list to the node)
+#ifdef RT_SCENE_PROBE
+                                atomicAdd(&g_probe_total[1], 1ull);  // double-precision sphere tests of leaf sets
+#endif
                                 const SphereExact se = set.spheres.exact[j];
                                 const int id = S.set_nodes[first_slot + j];
                                 double t;
@@ -444,6 +447,9 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                             if (set.boxes.n > 0) {
                                 const int first_box = first_slot + set.spheres.n;
                                 const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, [&](int j, SetHit& best) {
+#ifdef RT_SCENE_PROBE
+                                    atomicAdd(&g_probe_total[6], 1ull);  // double-precision box tests of leaf sets
+#endif
                                     const BoxExact be = set.boxes.exact[j];
                                     const int side = hit_box6(be.corner, loc, T_MIN, best.t);
                                     if (side >= 0) {
