@@ -94,6 +94,14 @@ __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// (time - time0) / (time1 - time0) of moving_sphere::center (B2/moving_sphere.h:28).  Over the interval [0, 1] -- the
+// one every moving sphere of the reference has -- the quotient is `time` itself, bit for bit (time - 0 = time,
+// 1 - 0 = 1, time / 1 = time), and the division is skipped unless some lane of the wave holds another interval.
+__device__ __forceinline__ double motion_fraction(double time, double time0, double time1) {
+    if (time0 == 0.0 && time1 == 1.0) return time;
+    return (time - time0) / (time1 - time0);
+}
+
 // n / width for n < 2^28 with the multiplier and shift of make_width_divider (rt_internal.h)
 __device__ __forceinline__ uint32_t div_by_width(uint32_t n, uint32_t mul, uint32_t shift) {
     return (uint32_t)(((uint64_t)n * (uint64_t)mul) >> shift);

@@ -155,7 +155,7 @@ __device__ __forceinline__ bool hit_sphere(d3 center, double radius, const Ray& 
 __device__ __forceinline__ d3 moving_center(const SceneDev& S, const SceneNode& n, double tm) {
     const d3 c0{n.p[0], n.p[1], n.p[2]}, c1{n.p[3], n.p[4], n.p[5]};
     const double time0 = S.extra[n.c], time1 = S.extra[n.c + 1];
-    return c0 + ((tm - time0) / (time1 - time0)) * (c1 - c0);
+    return c0 + motion_fraction(tm, time0, time1) * (c1 - c0);
 }
 
 // xy_rect / xz_rect / yz_rect ::hit up to acceptance (B2/aarect.h:28-34, 70-76, 112-118): the plane is axis ka = k,

@@ -209,7 +209,7 @@ __device__ __forceinline__ d3 center_at(const SphereSetDev& S, int j, const Sphe
     d3 center{e.cx, e.cy, e.cz};
     if constexpr (TIMED) {
         const SphereMotion mv = S.motion[j];
-        if (mv.moving != 0) center = center + ((tm - mv.time0) / (mv.time1 - mv.time0)) * (d3{mv.c1x, mv.c1y, mv.c1z} - center);
+        if (mv.moving != 0) center = center + motion_fraction(tm, mv.time0, mv.time1) * (d3{mv.c1x, mv.c1y, mv.c1z} - center);
     }
     return center;
 }
