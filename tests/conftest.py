@@ -5,6 +5,9 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first, before anything loads libraytracing_amd.so: PyTorch ships its own HIP runtime
+#                              (same soname as the system's), and a process must settle on one copy before either
+#                              library touches the GPU; some tests hand torch tensors to the library
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -16,9 +16,15 @@ from raytracing_amd import abi, lib  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 63
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-scene = abi.load_scene(os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc"))
-cam = lib.camera((12, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
-W, H = 1200, 800
+which = sys.argv[3] if len(sys.argv) > 3 else "c2"   # c2 | bouncing (config 3, the book-2 variant of the kernel)
+if which == "bouncing":
+    scene = abi.load_scene(os.path.join(ROOT, "tests", "golden", "scene_b2_bouncing.rtsc"))
+    cam = lib.camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 16.0 / 9.0, 0.1, 10.0, 0.0, 1.0)
+    W, H = 1200, 675
+else:
+    scene = abi.load_scene(os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc"))
+    cam = lib.camera((12, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    W, H = 1200, 800
 dev = torch.device("cuda", 0)
 s = torch.cuda.Stream(device=dev)
 ctx = lib.Context(0, s.cuda_stream)
