@@ -33,6 +33,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                           "(there is no CPU fallback)")
+    # PyTorch ships its own copy of the HIP runtime under the system's soname.  A process that hands torch tensors to
+    # this library (tests, bench.py) must use ONE copy: if torch is installed it is imported first, so that the
+    # library's libamdhip64 dependency resolves to the copy torch has already loaded (loaded the other way round,
+    # torch finds no GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     ctx_p = C.c_void_p
     L.rt_get_device_count.restype = C.c_int
