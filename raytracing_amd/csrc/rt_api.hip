@@ -554,8 +554,7 @@ static int build_sphere_clusters(rt_context* ctx, const std::vector<ScreenSphere
     if ((rc = to_device(ctx, wide_pairs, &C.wide_pairs)) != RT_OK) return rc;
     if ((rc = to_device(ctx, wide_members, &C.wide_members)) != RT_OK) return rc;
     C.n_wide = n_wide;
-    C.cover = (float)cover;
-    if ((double)C.cover > cover) C.cover = std::nextafterf(C.cover, 0.0f);  // never claim more than the margin covers
+    C.cover = cover;
     C.n_clusters = n_clusters;
     return RT_OK;
 }
@@ -658,8 +657,7 @@ static int build_box_set(rt_context* ctx, const rt_scene_desc* sc, const std::ve
     if ((rc = to_device(ctx, screen, &B.screen)) != RT_OK) return rc;
     if ((rc = to_device(ctx, exact, &B.exact)) != RT_OK) return rc;
     B.n = n;
-    B.cover = (float)cover;
-    if ((double)B.cover > cover) B.cover = std::nextafterf(B.cover, 0.0f);  // never claim more than the margin covers
+    B.cover = cover;
 
     // Two-level form: clusters by position of the box centres; a cluster's box is the union of its members' boxes,
     // widened like theirs (the same bound on the same arithmetic); members keep their own images.
@@ -1260,6 +1258,8 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
         A.width = p->width;
         A.height = p->height;
         A.wdiv = make_width_divider(p->width);
+        A.width_m1 = (double)(p->width - 1);
+        A.height_m1 = (double)(p->height - 1);
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;
@@ -1289,6 +1289,8 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
         A.width = p->width;
         A.height = p->height;
         A.wdiv = make_width_divider(p->width);
+        A.width_m1 = (double)(p->width - 1);
+        A.height_m1 = (double)(p->height - 1);
         A.sample_begin = p->sample_begin;
         A.sample_count = p->sample_count;
         A.max_depth = p->max_depth;

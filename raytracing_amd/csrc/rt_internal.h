@@ -59,8 +59,8 @@ struct BoxPair {
 struct SphereClustersDev {
     int32_t n_clusters;  // 0: the set has no two-level form
     int32_t n_wide;
-    float cover;         // the box margins hold for rays whose origin coordinates are at most this in magnitude
-    int32_t pad;
+    double cover;        // the box margins hold for rays whose origin coordinates are at most this in magnitude (held
+                         // as a double: it is compared with doubles, and a converted float would sit in a vector register)
     const BoxPair* boxes;       // per cluster, padded to whole groups of SCREEN_GROUP
     const SpherePair* pairs;    // CLUSTER_SIZE / 2 per cluster; padding slots never yield a candidate
     const uint16_t* members;    // CLUSTER_SIZE per cluster: index in the set, NO_MEMBER for padding
@@ -94,7 +94,8 @@ struct BoxExact {
 };
 struct BoxSetDev {
     int32_t n;
-    float cover;            // the margin holds for rays whose origin coordinates are at most this in magnitude
+    int32_t pad0;
+    double cover;           // the margin holds for rays whose origin coordinates are at most this in magnitude
     const BoxPair* screen;  // padded to whole groups of SCREEN_GROUP boxes
     const BoxExact* exact;  // per box, in set order
     BoxClustersDev clusters;
@@ -140,6 +141,7 @@ struct RenderArgs {
     CameraDev cam;
     int32_t width, height;
     WidthDivider wdiv;
+    double width_m1, height_m1;  // (double)(width - 1), (double)(height - 1): the jitter's divisors, B1/RayTracing.cpp:120-121
     int32_t sample_begin, sample_count;
     int32_t max_depth;
     int32_t item_cap;       // longest run of samples of one pixel that forms a work item (see ItemPlan)
@@ -239,6 +241,7 @@ struct SceneRenderArgs {
     CameraDev cam;
     int32_t width, height;
     WidthDivider wdiv;
+    double width_m1, height_m1;
     int32_t sample_begin, sample_count;
     int32_t max_depth;
     int32_t item_cap;

@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         {   // the lanes that start a sample; their camera rays come from Philox blocks the whole wave computes
             const bool start = !active && w.has_item;
             const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
-            camera_ray_for_lanes<true, SCENE_WAVE_BLOCKS>(start, cam, A.width, A.height, (int)(w.pixel - row * (uint32_t)A.width), A.height - 1 - (int)row,
+            camera_ray_for_lanes<true, SCENE_WAVE_BLOCKS>(start, cam, A.width_m1, A.height_m1, (int)(w.pixel - row * (uint32_t)A.width), A.height - 1 - (int)row,
                                        w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane, nullptr, r.o, r.d, tm);
             if (start) {
                 T = d3{1, 1, 1};

@@ -86,13 +86,14 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     // per-lane path state
     bool active = false;
     uint32_t bounce = 0;
-    int depth_left = 0;
     d3 o{0, 0, 0}, d{0, 0, 1}, T{1, 1, 1};
     double tm = 0.0;  // ray::time(), the same for every segment of a path (TIMED only)
     LaneWork w{};
     WaveWork wq{};
     const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6], plan.batch, plan.exclusive};
-    uint32_t n_samples = 0, n_rays = 0, n_bad = 0, n_overflow = 0;
+    // statistics of the wave (counted with population counts of lane masks: scalar registers, not one per lane)
+    uint32_t n_samples = 0, n_rays = 0;
+    uint32_t n_bad = 0, n_overflow = 0;  // per lane: rare events counted where they happen
 #ifdef RT_TAIL_PROBE
     const uint64_t pr_t0 = wall_clock64();
     uint64_t pr_tq = 0, pr_iters = 0, pr_iters_q = 0, pr_lanes_q = 0, pr_lanes = 0;
@@ -109,20 +110,19 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                 const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
                 const int i = (int)(w.pixel - row * (uint32_t)A.width);
                 const int j = A.height - 1 - (int)row;  // row 0 = top = j = H-1
-                camera_ray_for_lanes<TIMED, RT_COOP_CAMERA != 0>(start, cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0,
+                camera_ray_for_lanes<TIMED, RT_COOP_CAMERA != 0>(start, cam, A.width_m1, A.height_m1, i, j, w.pixel, (uint32_t)w.s_cur, A.key0,
                                                                  A.key1, lane, nullptr, o, d, tm);
             } else if (start) {  // (the book-2 variant is at its register limit: every lane computes its own blocks, in the branch)
                 const int i = (int)(w.pixel % (uint32_t)A.width);
                 const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);
-                camera_ray_for_lanes<TIMED, false>(true, cam, A.width, A.height, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane,
+                camera_ray_for_lanes<TIMED, false>(true, cam, A.width_m1, A.height_m1, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane,
                                                    nullptr, o, d, tm);
             }
+            n_samples += (uint32_t)__popcll(ballot(start));
             if (start) {
                 T = d3{1, 1, 1};
-                depth_left = A.max_depth;
                 bounce = 0;
                 active = true;
-                ++n_samples;
             }
         }
         // ---- closest hit (all lanes together)
@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
 #ifdef RT_PROBE_SPLIT
         pc.mark(SEC_SCREEN_SPARSE);
 #endif
+        n_rays += (uint32_t)__popcll(ballot(on));
         if (on) {
-            ++n_rays;
             bool done = false;
             d3 L_end{0, 0, 0};
             SphereExact e{0, 0, 0, 1};
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     o = p;
                     d = nd;
                     ++bounce;
-                    if (--depth_left <= 0) done = true;  // B1/RayTracing.cpp:15: the next call returns black
+                    if ((int)bounce >= A.max_depth) done = true;  // B1/RayTracing.cpp:15: the next call (depth 0) returns black
                 }
             }
             if (done) {
@@ -254,11 +254,9 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     }
 #endif
     // ---- statistics: one atomic per counter per wave
-    uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad, v3 = n_overflow;
+    uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad, v3 = n_overflow;  // v0, v1: already the wave's totals
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        v0 += __shfl_xor(v0, off);
-        v1 += __shfl_xor(v1, off);
         v2 += __shfl_xor(v2, off);
         v3 += __shfl_xor(v3, off);
     }

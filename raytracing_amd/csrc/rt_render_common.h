@@ -9,11 +9,12 @@ namespace rtd {
 
 // ---------------------------------------------------------------- camera
 // camera::get_ray (B1/camera.h:34-39) for pixel column i, reference row j, sample `sample`.
-__device__ __forceinline__ void camera_ray(const CameraDev& C, int W, int H, int i, int j, uint32_t pixel,
+// wm1, hm1 = (double)(W - 1), (double)(H - 1).
+__device__ __forceinline__ void camera_ray(const CameraDev& C, double wm1, double hm1, int i, int j, uint32_t pixel,
                                            uint32_t sample, uint32_t k0, uint32_t k1, d3& o, d3& d) {
     u32x4 w = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
-    const double s = (i + u01(w.x)) / (W - 1);  // B1/RayTracing.cpp:120-121
-    const double t = (j + u01(w.y)) / (H - 1);
+    const double s = (i + u01(w.x)) / wm1;  // B1/RayTracing.cpp:120-121
+    const double t = (j + u01(w.y)) / hm1;
     double px = u_range(w.z, -1, 1), py = u_range(w.w, -1, 1);
     for (uint32_t k = 1; px * px + py * py + 0.0 * 0.0 >= 1; ++k) {  // random_in_unit_disk
         if (k & 1u) {  // a new block every second attempt
@@ -127,12 +128,12 @@ __device__ __forceinline__ void philox_blocks_for_lanes(bool want, uint32_t c0, 
 #define RT_COOP_SHADE 1
 #endif
 template <bool TIMED, bool COOP = (RT_COOP_CAMERA != 0)>
-__device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev& C, int W, int H, int i, int j, uint32_t pixel,
+__device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev& C, double wm1, double hm1, int i, int j, uint32_t pixel,
                                                      uint32_t sample, uint32_t k0, uint32_t k1, int lane, uint8_t* owners, d3& o,
                                                      d3& d, double& tm) {
     if constexpr (!COOP) {
         if (start) {
-            camera_ray(C, W, H, i, j, pixel, sample, k0, k1, o, d);
+            camera_ray(C, wm1, hm1, i, j, pixel, sample, k0, k1, o, d);
             if constexpr (TIMED) {
                 tm = C.time0;
                 if (C.time0 != C.time1) tm = u_range(philox4x32_10(pixel, sample, 0u, TRY_TIME, k0, k1).x, C.time0, C.time1);
@@ -142,8 +143,8 @@ __device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev
     }
     u32x4 b[2];
     philox_blocks_for_lanes<2>(start, pixel, sample, 0u, 0u, TIMED ? TRY_TIME : 0u, k0, k1, lane, owners, b);
-    const double s = (i + u01(b[0].x)) / (W - 1);  // B1/RayTracing.cpp:120-121
-    const double t = (j + u01(b[0].y)) / (H - 1);
+    const double s = (i + u01(b[0].x)) / wm1;  // B1/RayTracing.cpp:120-121
+    const double t = (j + u01(b[0].y)) / hm1;
     double px = u_range(b[0].z, -1, 1), py = u_range(b[0].w, -1, 1);
     bool need = start && px * px + py * py + 0.0 * 0.0 >= 1;  // random_in_unit_disk
     auto attempt = [&](uint32_t x, uint32_t y) {

@@ -109,14 +109,14 @@ struct BoxScreenRay {
     bool covered;
 };
 
-__device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, float cover) {
+__device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, double cover) {
     BoxScreenRay s;
     s.covered = true;
     const double ok[3] = {o.x, o.y, o.z}, dk[3] = {d.x, d.y, d.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double ad = fabs(dk[k]), ao = fabs(ok[k]);
-        if (!(ad >= 1e-30 && ad <= 1e30 && ao <= (double)cover)) s.covered = false;
+        if (!(ad >= 1e-30 && ad <= 1e30 && ao <= cover)) s.covered = false;
         const double inv = 1.0 / dk[k];
         s.inv[k] = splat(inv);
         s.ainv[k] = f2{fabsf(s.inv[k].x), fabsf(s.inv[k].x)};
