@@ -43,6 +43,9 @@ namespace rtd {
 #endif
 // The book-2 variant also fits 4 waves/SIMD (6 spilled registers outside the loop; measured 3 % faster than at 3
 // waves) now that the checker texture evaluates no sin() inline.
+#ifndef RT_TIMED_WAVE_BLOCKS
+#define RT_TIMED_WAVE_BLOCKS 0
+#endif
 #ifndef RT_MIN_WAVES_TIMED
 #define RT_MIN_WAVES_TIMED 4
 #endif
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, A.pixel_pass != 0);
     __shared__ AccumCache s_acc[4];
-    constexpr bool WAVE_BLOCKS = !TIMED && (RT_COOP_SHADE != 0);  // Philox blocks of the rejection loops computed wave-wide
+    constexpr bool WAVE_BLOCKS = (!TIMED || RT_TIMED_WAVE_BLOCKS != 0) && (RT_COOP_SHADE != 0);  // Philox blocks of the rejection loops computed wave-wide
     accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
 
     // per-lane path state
