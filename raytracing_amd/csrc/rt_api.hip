@@ -977,6 +977,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     if (!sets.empty()) features |= scene_feature_bit_for_node(DEV_NODE_LEAF_SET);
     for (int i = 0; i < sc->n_textures; ++i) features |= scene_feature_bit_for_texture(sc->textures[i].kind);
     for (int i = 0; i < sc->n_materials; ++i) features |= scene_feature_bit_for_material(sc->materials[i].kind);
+    for (const TopEntry& te : tops) features |= scene_feature_bit_for_top(te.end.kind);
     if (const char* v = std::getenv("RT_SCENE_VARIANT")) {
         if (std::strcmp(v, "all") == 0) features = ~0;
     }

@@ -269,6 +269,7 @@ void scene_probe_dump();  // debug build: prints and clears the traversal counte
 int scene_feature_bit_for_node(int node_kind);  // F_* bit a node / texture / material kind needs, 0 if none
 int scene_feature_bit_for_texture(int texture_kind);
 int scene_feature_bit_for_material(int material_kind);
+int scene_feature_bit_for_top(int end_kind);  // the stack-walk bit if a world object of this (device) kind needs it
 
 // Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.
 // `timed` selects the variant for book-2 sphere worlds (shutter time, moving spheres, checker textures).

@@ -55,7 +55,8 @@ enum : int {
     F_IS = 128,      // ray_color of book 3: light sampled by importance (RT_RENDER_IMPORTANCE); not part of F_ALL
     F_FLIP = 256,    // flip_face wrappers (book 3); not part of F_ALL, implies the instance machinery (F_XF)
     F_SET = 512,     // BVH subtrees of spheres / boxes evaluated as leaf sets (DEV_NODE_LEAF_SET); not part of F_ALL
-    F_EVERY = F_ALL | F_FLIP | F_SET,
+    F_STACK = 1024,  // some object of the world is walked through the per-lane stack (trace()); not part of F_ALL
+    F_EVERY = F_ALL | F_FLIP | F_SET | F_STACK,
 };
 static_assert(CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "the candidate lists of a leaf set use the stack's memory (a set is evaluated while the stack is empty)");
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
@@ -481,6 +482,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             continue;
         }
     }
+    if constexpr ((F & F_STACK) != 0) {
     int sp = 0;
     if (on) stack[(sp++) * 64 + lane] = (uint32_t)top_node;
 
@@ -552,6 +554,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
         }
     }
     PROBE_MARK(PS_STACK_WALK);
+    }
     }
     return h;
 }
@@ -1009,10 +1012,22 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
 #ifndef RT_SCENE_WAVES_SET
 #define RT_SCENE_WAVES_SET 2
 #endif
-constexpr int V_A = F_MOVING | F_CHECKER;                    // spheres under a BVH (bouncing spheres)
-constexpr int V_B = F_RECT | F_XF | F_MEDIUM;                // boxes, instances, smoke (Cornell boxes)
-constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE;  // textured spheres and lights
-constexpr int V_IS = F_RECT | F_XF | F_FLIP | F_IS;          // book 3's Cornell box, light sampled by importance
+constexpr int V_A = F_MOVING | F_CHECKER | F_STACK;                    // spheres under a BVH (bouncing spheres)
+constexpr int V_B = F_RECT | F_XF | F_MEDIUM | F_STACK;                // boxes, instances, smoke (Cornell boxes)
+constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE | F_STACK;  // textured spheres and lights
+constexpr int V_IS = F_RECT | F_XF | F_FLIP | F_IS | F_STACK;          // book 3's Cornell box, light sampled by importance
+#ifndef RT_SCENE_WAVES_FLAT
+#define RT_SCENE_WAVES_FLAT 2
+#endif
+#ifndef RT_SCENE_WAVES_B_FLAT
+#define RT_SCENE_WAVES_B_FLAT 4
+#endif
+#ifndef RT_SCENE_WAVES_C_FLAT
+#define RT_SCENE_WAVES_C_FLAT 2
+#endif
+#ifndef RT_SCENE_WAVES_IS_FLAT
+#define RT_SCENE_WAVES_IS_FLAT 4
+#endif
 typedef void (*scene_kernel_t)(const SceneRenderArgs);
 struct SceneVariant {
     int features;
@@ -1020,11 +1035,15 @@ struct SceneVariant {
 };
 static const SceneVariant g_variants[] = {
     {V_A, k_render_scene<V_A, RT_SCENE_WAVES_A>},
+    {V_B & ~F_STACK, k_render_scene<V_B & ~F_STACK, RT_SCENE_WAVES_B_FLAT>},  // ... every object of the world in the wave-level walk
     {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
+    {V_C & ~F_STACK, k_render_scene<V_C & ~F_STACK, RT_SCENE_WAVES_C_FLAT>},
     {V_C, k_render_scene<V_C, 2>},
-    {F_ALL, k_render_scene<F_ALL, RT_SCENE_MIN_WAVES>},
-    {F_ALL | F_SET, k_render_scene<F_ALL | F_SET, RT_SCENE_WAVES_SET>},
+    {F_ALL | F_SET, k_render_scene<F_ALL | F_SET, RT_SCENE_WAVES_FLAT>},  // no object needs the stack (the Next-Week final scene)
+    {F_ALL | F_STACK, k_render_scene<F_ALL | F_STACK, RT_SCENE_MIN_WAVES>},
+    {F_ALL | F_SET | F_STACK, k_render_scene<F_ALL | F_SET | F_STACK, RT_SCENE_WAVES_SET>},
     {F_EVERY, k_render_scene<F_EVERY, RT_SCENE_MIN_WAVES>},
+    {V_IS & ~F_STACK, k_render_scene<V_IS & ~F_STACK, RT_SCENE_WAVES_IS_FLAT>},
     {V_IS, k_render_scene<V_IS, 2>},
     {F_EVERY | F_IS, k_render_scene<F_EVERY | F_IS, 2>},
 };
@@ -1093,6 +1112,11 @@ int scene_feature_bit_for_texture(int kind) {
     return kind == RT_TEX_CHECKER ? F_CHECKER : kind == RT_TEX_NOISE ? F_NOISE : kind == RT_TEX_IMAGE ? F_IMAGE : 0;
 }
 int scene_feature_bit_for_material(int kind) { return kind == RT_MAT_ISOTROPIC ? F_MEDIUM : 0; }
+int scene_feature_bit_for_top(int end_kind) {  // end_kind: the device kind of a world object below its instance chain
+    const bool in_the_wave_walk = (end_kind >= RT_NODE_SPHERE && end_kind <= RT_NODE_YZ_RECT) || end_kind == DEV_NODE_BOX6 ||
+                                  end_kind == RT_NODE_MEDIUM || end_kind == DEV_NODE_LEAF_SET;
+    return in_the_wave_walk ? 0 : F_STACK;
+}
 
 int render_scene_blocks_per_cu(int features, bool importance) {
     int n = 0;
