@@ -841,14 +841,14 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
 
     bool active = false;
     uint32_t bounce = 0;
-    int depth_left = 0;
     Ray r{d3{0, 0, 0}, d3{0, 0, 1}};
     d3 T{1, 1, 1};
     double tm = 0.0;
     LaneWork w{};
     WaveWork wq{};
     const WorkQueues Q{A.item_counter, A.n_items, A.accum, nullptr, plan.batch, false};  // no accumulation cache: these kernels are short of registers
-    uint32_t n_samples = 0, n_rays = 0, n_bad = 0;
+    uint32_t n_samples = 0, n_rays = 0;  // of the wave (population counts of lane masks: scalar registers)
+    uint32_t n_bad = 0;                  // per lane
 
 #ifdef RT_SCENE_PROBE
     unsigned long long probe_t = clock64();
@@ -860,12 +860,11 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
             const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
             camera_ray_for_lanes<true, SCENE_WAVE_BLOCKS>(start, cam, A.width_m1, A.height_m1, (int)(w.pixel - row * (uint32_t)A.width), A.height - 1 - (int)row,
                                        w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane, nullptr, r.o, r.d, tm);
+            n_samples += (uint32_t)__popcll(ballot(start));
             if (start) {
                 T = d3{1, 1, 1};
-                depth_left = A.max_depth;
                 bounce = 0;
                 active = true;
-                ++n_samples;
             }
         }
         const bool on = active;
@@ -891,8 +890,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                                           (!importance && m.kind == RT_MAT_ISOTROPIC));
         const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
         const d3 rs = random_in_unit_sphere_for_lanes<SCENE_WAVE_BLOCKS>(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1, lane, nullptr);
+        n_rays += (uint32_t)__popcll(ballot(on));
         if (on) {
-            ++n_rays;
             bool done = false;
             d3 L_end{0, 0, 0};
             if (!hit) {
@@ -949,7 +948,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                     r.o = s.p;
                     r.d = nd;
                     ++bounce;
-                    if (--depth_left <= 0) done = true;
+                    if ((int)bounce >= A.max_depth) done = true;  // B2/RayTracing.cpp:21-22: the next call (depth 0) returns black
                 }
             }
             if (done) {
@@ -961,13 +960,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         PROBE_MARK(PS_SHADE);
     }
 
-    uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad;
+    uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad;  // v0, v1: already the wave's totals
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        v0 += __shfl_xor(v0, off);
-        v1 += __shfl_xor(v1, off);
-        v2 += __shfl_xor(v2, off);
-    }
+    for (int off = 32; off > 0; off >>= 1) v2 += __shfl_xor(v2, off);
     if (lane == 0) {
         atomicAdd((unsigned long long*)&A.stats[0], (unsigned long long)v0);
         atomicAdd((unsigned long long*)&A.stats[1], (unsigned long long)v1);
