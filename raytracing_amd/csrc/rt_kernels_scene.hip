@@ -820,7 +820,10 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
 constexpr bool SCENE_WAVE_BLOCKS = RT_SCENE_WAVE_BLOCKS != 0;
 template <int F, int MIN_WAVES>
 __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRenderArgs A) {
-    __shared__ uint32_t s_stack[4][STACK_CAP * 64];
+    // LDS per wave: the traversal stack; without it the candidate lists of the leaf sets; without those nothing (a
+    // variant that needs neither is not held back by LDS: 4 workgroups of 40 KB would not fit a CU's 160 KB)
+    constexpr int STACK_WORDS = (F & F_STACK) != 0 ? STACK_CAP * 64 : ((F & F_SET) != 0 ? CAND_CAP * 32 + ROW_WORDS * 64 : 64);
+    __shared__ uint32_t s_stack[4][STACK_WORDS];
     // The camera (21 doubles) is needed once per sample; read from the kernel arguments it would sit in 42 scalar
     // registers for the whole kernel and push hot values out.  One copy per wave in LDS, read back where it is used.
     __shared__ CameraDev s_cam[4];
