@@ -676,6 +676,68 @@ __device__ __forceinline__ double perlin_turb(const rt_perlin& pn, d3 p) {  // B
     return fabs(accum);
 }
 
+// perlin::turb for the lanes with `want` set, computed by the whole wave.  A noise texture is met by one or two lanes
+// of a wave at a time, and evaluating it there keeps the other lanes waiting through 7 octaves x 8 lattice corners
+// (about 1400 vector instructions and 340 loads).  Here the 56 terms of one lookup are spread over 56 lanes -- lane
+// 8 o + c computes corner c (in the loop order of B2/perlin.h:92-101) of octave o, whose point is p 2^o (six exact
+// doublings) -- and then added up in the reference's order: the eight terms of an octave one after the other into 0.0,
+// the seven octaves one after the other with their weights (B2/perlin.h:55-59).  Same operations on the same values as
+// perlin_turb: the result is the same bit for bit.  One lookup after the other; beyond RT_PERLIN_SPREAD_MAX wanting
+// lanes every lane evaluates its own.  All 64 lanes must call it.
+#ifndef RT_PERLIN_SPREAD_MAX
+#define RT_PERLIN_SPREAD_MAX 12
+#endif
+__device__ __forceinline__ double lane_value(double v, int src_lane) {  // v of lane src_lane (the same for the whole wave)
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_value_of(double v, int src_lane) {  // src_lane may differ from lane to lane
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double perlin_turb_for_lanes(const SceneDev& S, bool want, int perlin_index, d3 p, int lane) {
+    double result = 0.0;
+    const uint64_t wanting = ballot(want);
+    if (__popcll(wanting) > RT_PERLIN_SPREAD_MAX) {
+        if (want) result = perlin_turb(S.perlins[perlin_index], p);
+        return result;
+    }
+    for (uint64_t m = wanting; m != 0ull; m &= m - 1ull) {
+        const int src = __builtin_ctzll(m);
+        const rt_perlin& pn = S.perlins[__builtin_amdgcn_readlane(perlin_index, src)];
+        const d3 q{lane_value(p.x, src), lane_value(p.y, src), lane_value(p.z, src)};
+        const int octave = lane >> 3, di = (lane >> 2) & 1, dj = (lane >> 1) & 1, dk = lane & 1;
+        double term = 0.0;
+        if (lane < 56) {  // one term of perlin_noise at q 2^octave, B2/perlin.h:24-48, 86-104
+            const double scale = (double)(1 << octave);
+            const d3 tp{q.x * scale, q.y * scale, q.z * scale};
+            const double u = tp.x - floor(tp.x), v = tp.y - floor(tp.y), w = tp.z - floor(tp.z);
+            const int i = floor_to_int(tp.x), j = floor_to_int(tp.y), k = floor_to_int(tp.z);
+            const double uu = u * u * (3 - 2 * u), vv = v * v * (3 - 2 * v), ww = w * w * (3 - 2 * w);
+            const int idx = pn.perm_x[((uint32_t)i + (uint32_t)di) & 255u] ^ pn.perm_y[((uint32_t)j + (uint32_t)dj) & 255u] ^
+                            pn.perm_z[((uint32_t)k + (uint32_t)dk) & 255u];
+            const d3 c{pn.ranvec[idx][0], pn.ranvec[idx][1], pn.ranvec[idx][2]};
+            const d3 weight_v{u - di, v - dj, w - dk};
+            term = (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * dot(c, weight_v);
+        }
+        double noise = 0.0;  // of this lane's octave: its eight terms in order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) noise += lane_value_of(term, (lane & ~7) + c);
+        double accum = 0.0, weight = 1.0;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+            accum += weight * lane_value(noise, 8 * o);
+            weight *= 0.5;
+        }
+        if (lane == src) result = fabs(accum);
+    }
+    return result;
+}
+
 __device__ __forceinline__ double clampd(double x, double lo, double hi) {  // B2/rtweekend.h:47-51
     if (x < lo) return lo;
     if (x > hi) return hi;
@@ -683,17 +745,31 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {  // B
 }
 
 // texture::value (B2/texture.h).  Checker textures are followed iteratively (at most 4 levels).
+// The texture that answers for texture ti at point p: checker textures followed down to the first that is none
+// (at most 4 levels: -1 beyond, value() is black there).
 template <int F>
-__device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& s) {
-    for (int level = 0; level < 4; ++level) {
-        const TextureDev t = S.textures[ti];
-        if ((F & F_CHECKER) != 0 && t.kind == RT_TEX_CHECKER) {
-            ti = checker_sines_negative(s.p) ? t.b : t.a;
-            continue;
+__device__ __forceinline__ int texture_resolve(const SceneDev& S, int ti, d3 p) {
+    if constexpr ((F & F_CHECKER) != 0) {
+        for (int level = 0; level < 4; ++level) {
+            const TextureDev t = S.textures[ti];
+            if (t.kind != RT_TEX_CHECKER) return ti;
+            ti = checker_sines_negative(p) ? t.b : t.a;
         }
+        return -1;
+    }
+    return ti;
+}
+
+// texture::value (B2/texture.h) of a texture that is no checker (texture_resolve); turb = perlin::turb at s.p if it is a
+// noise texture (perlin_turb_for_lanes).
+template <int F>
+__device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& s, double turb) {
+    if (ti < 0) return d3{0, 0, 0};
+    {
+        const TextureDev t = S.textures[ti];
         if (t.kind == RT_TEX_SOLID) return d3{t.p[0], t.p[1], t.p[2]};
         if ((F & F_NOISE) != 0 && t.kind == RT_TEX_NOISE) {
-            const double f = 1 + sin(t.p[0] * s.p.z + 10 * perlin_turb(S.perlins[t.a], s.p));
+            const double f = 1 + sin(t.p[0] * s.p.z + 10 * turb);
             return f * (0.5 * d3{1, 1, 1});
         }
         // RT_TEX_IMAGE, B2/texture.h:85-104
@@ -717,7 +793,6 @@ __device__ __forceinline__ d3 texture_value(const SceneDev& S, int ti, Surface& 
         const uint8_t* px = im.rgb + (size_t)j * 3 * (size_t)im.width + (size_t)i * 3;
         return d3{color_scale * px[0], color_scale * px[1], color_scale * px[2]};
     }
-    return d3{0, 0, 0};
 }
 
 // ---------------------------------------------------------------- "The Rest Of Your Life"
@@ -893,6 +968,23 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                                           (!importance && m.kind == RT_MAT_ISOTROPIC));
         const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
         const d3 rs = random_in_unit_sphere_for_lanes<SCENE_WAVE_BLOCKS>(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1, lane, nullptr);
+        // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code); the
+        // turbulence of the lanes that met a noise texture is computed by the whole wave
+        const bool wants_texture = hit && (m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
+                                           (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face)));
+        int tex_index = -1;
+        double turb = 0.0;
+        if (wants_texture) tex_index = texture_resolve<F>(S, m.tex, s.p);
+        if constexpr ((F & F_NOISE) != 0) {
+            int perlin_index = 0;
+            bool noise = false;
+            if (tex_index >= 0) {
+                const TextureDev t = S.textures[tex_index];
+                noise = t.kind == RT_TEX_NOISE;
+                perlin_index = t.a;
+            }
+            turb = perlin_turb_for_lanes(S, noise, perlin_index, s.p, lane);
+        }
         n_rays += (uint32_t)__popcll(ballot(on));
         if (on) {
             bool done = false;
@@ -909,11 +1001,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
             } else {
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
-                // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code)
-                const bool wants_texture = m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
-                                           (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face));
                 d3 tex{0, 0, 0};
-                if (wants_texture) tex = texture_value<F>(S, m.tex, s);
+                if (wants_texture) tex = texture_value<F>(S, tex_index, s, turb);
                 if (importance && m.kind == RT_MAT_LAMBERTIAN) {  // book 3: mixture of light and cosine densities
                     attenuation = importance_bounce(S, s.p, s.normal, tex, g, block0, nd);
                 } else if (importance && m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
