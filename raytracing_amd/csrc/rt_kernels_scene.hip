@@ -1104,13 +1104,13 @@ constexpr int V_B = F_RECT | F_XF | F_MEDIUM | F_STACK;                // boxes,
 constexpr int V_C = F_RECT | F_NOISE | F_CHECKER | F_IMAGE | F_STACK;  // textured spheres and lights
 constexpr int V_IS = F_RECT | F_XF | F_FLIP | F_IS | F_STACK;          // book 3's Cornell box, light sampled by importance
 #ifndef RT_SCENE_WAVES_FLAT
-#define RT_SCENE_WAVES_FLAT 2
+#define RT_SCENE_WAVES_FLAT 3
 #endif
 #ifndef RT_SCENE_WAVES_B_FLAT
 #define RT_SCENE_WAVES_B_FLAT 4
 #endif
 #ifndef RT_SCENE_WAVES_C_FLAT
-#define RT_SCENE_WAVES_C_FLAT 2
+#define RT_SCENE_WAVES_C_FLAT 3
 #endif
 #ifndef RT_SCENE_WAVES_IS_FLAT
 #define RT_SCENE_WAVES_IS_FLAT 4
