@@ -326,6 +326,7 @@ static __device__ unsigned long long g_probe_total[16];  // [kind] entries, [12]
 // wave cycles per section of the render loop
 enum { PS_REFILL = 0, PS_TOP_PRIM, PS_TOP_BOX, PS_TOP_MEDIUM, PS_SET_SPHERES, PS_SET_BOXES, PS_STACK_WALK, PS_SHADE, PS_COUNT };
 static __device__ unsigned long long g_probe_cycles[PS_COUNT];
+static __device__ unsigned long long g_probe_mine[2][6];  // visits of a leaf set by the lanes that reached it: 1-4, 5-8, 9-16, 17-32, 33-64; [5] = lanes
 #define PROBE_MARK(k) do { const unsigned long long now_ = clock64(); if (lane == 0) atomicAdd(&g_probe_cycles[k], now_ - probe_t); probe_t = now_; } while (0)
 #else
 #define PROBE_MARK(k) do { } while (0)
@@ -413,6 +414,14 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     const bool mine = on && hit_aabb(n.p, loc, loc_inv, T_MIN, h.t);
                     if (ballot(mine) != 0ull) {
                         const LeafSetDev set = S.sets[n.a];
+#ifdef RT_SCENE_PROBE
+                        const int np = __popcll(ballot(mine));
+                        if (lane == 0) {
+                            const int kind_of_set = set.spheres.n > 0 ? 0 : 1;
+                            atomicAdd(&g_probe_mine[kind_of_set][np <= 4 ? 0 : np <= 8 ? 1 : np <= 16 ? 2 : np <= 32 ? 3 : 4], 1ull);
+                            atomicAdd(&g_probe_mine[kind_of_set][5], (unsigned long long)np);
+                        }
+#endif
                         const int first_slot = n.b;
                         const double loc_a = len2(loc.d);
                         uint16_t* list = (uint16_t*)stack;
@@ -1177,6 +1186,17 @@ void scene_probe_dump() {
     for (int k = 0; k < PS_COUNT; ++k)
         std::fprintf(stderr, "  wave cycles %-22s %14llu  %5.1f %%\n", sections[k], c[k], 100.0 * (double)c[k] / (double)(total ? total : 1));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cycles), z, sizeof(c));
+    unsigned long long mn[2][6];
+    if (hipMemcpyFromSymbol(mn, HIP_SYMBOL(g_probe_mine), sizeof(mn)) != hipSuccess) return;
+    for (int k = 0; k < 2; ++k) {
+        const unsigned long long visits = mn[k][0] + mn[k][1] + mn[k][2] + mn[k][3] + mn[k][4];
+        if (visits)
+            std::fprintf(stderr, "  leaf sets of %s: %llu wave visits (%.2f per trace), lanes per visit %.1f; visits by lanes 1-4 / 5-8 / 9-16 / 17-32 / 33-64: %.1f %.1f %.1f %.1f %.1f %%\n",
+                         k == 0 ? "spheres" : "boxes", visits, (double)visits / (double)h[14], (double)mn[k][5] / (double)visits,
+                         100.0 * mn[k][0] / visits, 100.0 * mn[k][1] / visits, 100.0 * mn[k][2] / visits, 100.0 * mn[k][3] / visits, 100.0 * mn[k][4] / visits);
+    }
+    unsigned long long zz[2][6] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_mine), zz, sizeof(zz));
 }
 #endif
 

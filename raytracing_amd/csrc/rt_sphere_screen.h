@@ -109,6 +109,58 @@ __device__ __forceinline__ f2 splat_from_lane_of(f2 v, int src_lane) {  // src_l
     return f2{f, f};
 }
 
+// First level of a two-level walk (queue_cluster_items below) for a wave in which few lanes hold a ray -- a set inside
+// a scene graph is reached by a handful of rays more often than not.  The wave turns by 90 degrees: lane t holds the
+// box of cluster t (64 clusters at a time), the rays are taken one after the other, their constants broadcast from the
+// owning lane, and the ballot of the lanes whose box the ray meets is the ray's list of clusters.  About 35 vector
+// instructions per ray and 64 clusters, against 19 per pair of clusters for all rays at once.  Same arithmetic as
+// box_screen_pair_ops, one box per lane.
+#ifndef RT_SPARSE_CLUSTER_MAX_RAYS
+#define RT_SPARSE_CLUSTER_MAX_RAYS 12
+#endif
+__device__ __forceinline__ float float_from_lane(float v, int src_lane) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src_lane));
+}
+__device__ __forceinline__ uint32_t queue_cluster_items_few_rays(const BoxPair* boxes, int n_clusters, const BoxScreenRay& br, uint64_t on_mask,
+                                                                 uint16_t* items, int lane, bool& dropped) {
+    uint32_t n_items = 0;
+    for (int first = 0; first < n_clusters; first += 64) {
+        const int c = first + lane;
+        const bool present = c < n_clusters;
+        const BoxPair* bp = boxes + ((present ? c : 0) >> 1);
+        const int half = c & 1;
+        const float mid[3] = {bp->mid[0][half], bp->mid[1][half], bp->mid[2][half]};
+        const float hw[3] = {bp->hw[0][half], bp->hw[1][half], bp->hw[2][half]};
+        for (uint64_t m = on_mask; m != 0ull; m &= m - 1ull) {
+            const int src = __builtin_ctzll(m);
+            float near_t[3], far_t[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float inv = float_from_lane(br.inv[k].x, src), ainv = float_from_lane(br.ainv[k].x, src);
+                const float tc = __builtin_fmaf(mid[k], inv, float_from_lane(br.c[k].x, src));
+                near_t[k] = __builtin_fmaf(hw[k], -ainv, tc);
+                far_t[k] = __builtin_fmaf(hw[k], ainv, tc);
+            }
+            const float far_all = fminf(fminf(far_t[0], far_t[1]), far_t[2]);
+            const float near_all = fmaxf(fmaxf(near_t[0], near_t[1]), near_t[2]);
+            const float q = fminf(far_all - near_all, far_all);
+            const bool meets = present && (__float_as_uint(q) >> 31) == 0u;
+            const uint64_t met = ballot(meets);
+            const uint32_t n_met = (uint32_t)__popcll(met);
+            if (n_items + n_met <= (uint32_t)ITEM_CAP) {
+                if (meets) {
+                    const uint32_t before_me = __builtin_amdgcn_mbcnt_hi((uint32_t)(met >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)met, 0u));
+                    items[n_items + before_me] = (uint16_t)((src << ITEM_CLUSTER_BITS) | c);
+                }
+                n_items += n_met;
+            } else if (n_met != 0u && lane == src) {
+                dropped = true;
+            }
+        }
+    }
+    return n_items;
+}
+
 // First level of a two-level walk: the wave tests every lane's ray against the boxes of all clusters (`boxes`, padded
 // to whole groups of SCREEN_GROUP) and queues one item, lane << ITEM_CLUSTER_BITS | cluster, per meeting in `items`
 // (ITEM_CAP slots; positions from the ballot, no atomics).  Returns the number of items; `dropped` is set in lanes that
@@ -117,6 +169,10 @@ __device__ __forceinline__ uint32_t queue_cluster_items(const BoxPair* boxes, in
                                                         uint16_t* items, int lane, bool& dropped) {
     uint32_t n_items = 0;  // the same in every lane
     dropped = false;
+    {
+        const uint64_t on_mask = ballot(on);
+        if (__popcll(on_mask) <= RT_SPARSE_CLUSTER_MAX_RAYS) return queue_cluster_items_few_rays(boxes, n_clusters, br, on_mask, items, lane, dropped);
+    }
     const ConstBoxPair* bp = (const ConstBoxPair*)boxes;
     const int n_groups = (n_clusters + SCREEN_GROUP - 1) / SCREEN_GROUP;
     for (int g = 0; g < n_groups; ++g) {
@@ -268,7 +324,8 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     br.covered = false;
     if (two_level) br = box_screen_prepare(o, d, S.clusters.cover);
     pc.mark(SEC_PREP);
-    if (__popcll(on_mask) <= (two_level ? SPARSE_MAX_RAYS_TWO_LEVEL : SPARSE_MAX_RAYS)) {
+    const bool by_clusters = two_level && ballot(on && !br.covered) == 0ull;
+    if (!by_clusters && __popcll(on_mask) <= (two_level ? SPARSE_MAX_RAYS_TWO_LEVEL : SPARSE_MAX_RAYS)) {
         for (int c = 0; c < S.n_chunks; ++c) {
             const SpherePair* mine = S.screen + (size_t)c * SPARSE_CHUNK_PAIRS + (size_t)lane * 4;
             const SpherePair p0 = mine[0], p1 = mine[1], p2 = mine[2], p3 = mine[3];
@@ -310,7 +367,7 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
             __builtin_amdgcn_wave_barrier();
         }
         pc.mark(SEC_SCREEN_SPARSE);
-    } else if (two_level && ballot(on && !br.covered) == 0ull) {
+    } else if (by_clusters) {
         screen_clusters(S, sr, br, on, list, rows, lane, cnt, pc);
         pc.mark(SEC_SCREEN_MEMBERS);
     } else {
