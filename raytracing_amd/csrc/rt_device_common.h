@@ -89,6 +89,34 @@ __device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {     
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// What the lanes of this wave wrote to LDS before is visible to all of them after.
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// A double of another lane: src_lane the same for the whole wave / different from lane to lane.
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_value_of(double v, int src_lane) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {  // the same in every lane
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)v, off);
+        v = other > v ? other : v;
+    }
+    return v;
+}
 // number of set bits of `m` below this lane
 __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -456,16 +456,16 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         if constexpr ((F & F_RECT) != 0) {
                             if (set.boxes.n > 0) {
                                 const int first_box = first_slot + set.spheres.n;
-                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, [&](int j, SetHit& best) {
+                                const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane,
+                                                                  [&](int j, d3 ro, d3 rd, double t_max, double& t) -> int {
 #ifdef RT_SCENE_PROBE
                                     atomicAdd(&g_probe_total[6], 1ull);  // double-precision box tests of leaf sets
 #endif
                                     const BoxExact be = set.boxes.exact[j];
-                                    const int side = hit_box6(be.corner, loc, T_MIN, best.t);
-                                    if (side >= 0) {
-                                        best.id = j;
-                                        best.aux = be.first_side + side;
-                                    }
+                                    const Ray ray{ro, rd};
+                                    t = t_max;
+                                    const int side = hit_box6(be.corner, ray, T_MIN, t);
+                                    return side >= 0 ? be.first_side + side : -1;
                                 });
                                 // A box side hit at exactly the sphere's t: bvh_node::hit accepts an equal root
                                 // (B2/bvh.h:99-100, B2/sphere.h:54), so the leaf the tree reaches LATER wins -- the
@@ -696,18 +696,6 @@ __device__ __forceinline__ double perlin_turb(const rt_perlin& pn, d3 p) {  // B
 #ifndef RT_PERLIN_SPREAD_MAX
 #define RT_PERLIN_SPREAD_MAX 12
 #endif
-__device__ __forceinline__ double lane_value(double v, int src_lane) {  // v of lane src_lane (the same for the whole wave)
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ double lane_value_of(double v, int src_lane) {  // src_lane may differ from lane to lane
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)b);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(b >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
 __device__ __forceinline__ double perlin_turb_for_lanes(const SceneDev& S, bool want, int perlin_index, d3 p, int lane) {
     double result = 0.0;
     const uint64_t wanting = ballot(want);

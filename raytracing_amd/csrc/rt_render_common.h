@@ -357,11 +357,6 @@ struct WorkQueues {
     bool exclusive;     // ItemPlan::exclusive: a pixel's sums reach memory from one wave only, through its cache
 };
 
-__device__ __forceinline__ void lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ void accum_cache_init(AccumCache* c, int lane) {
     if (lane < ACC_SLOTS) {
         c->tag[lane] = ACC_EMPTY;
