@@ -8,10 +8,6 @@
 
 namespace rtd {
 
-#ifndef RT_SPREAD_BOX_TESTS
-#define RT_SPREAD_BOX_TESTS 1
-#endif
-
 // Second level of the two-level walk, as screen_clusters does it for spheres: the queued (ray, cluster) items 64 at a
 // time, one per lane; the ray's constants by lane permutation, the cluster's members by vector loads, candidates to the
 // owning ray's list through the counters in LDS.
@@ -61,23 +57,6 @@ __device__ __forceinline__ void screen_box_clusters(const BoxSetDev& B, const Bo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     cnt = counts[lane];
 }
-
-// Double-precision tests handed round the wave.  After the screens a few lanes hold several candidates each and most
-// hold none (a set inside a scene graph: ~45 candidates on ~17 rays per visit of the wave, the busiest lane 5 or 6), and
-// a loop in which every lane works through its own list runs as long as the busiest lane.  Here the (ray, box) pairs are
-// numbered through the wave (prefix sum of the lanes' counts) and tested 64 at a time, one per lane, WHICHEVER lane the
-// ray belongs to: the ray's origin, direction and t_max arrive by lane permutation.  Results meet per ray in LDS: the
-// smallest t by a 64-bit unsigned minimum on its bit pattern (t >= t_min > 0: the patterns order like the values), then,
-// among the tests that reached that t, the largest member index -- "t smaller, or equal and index larger", the rule of
-// the per-lane loop below, which is the reference's own order of testing (see closest_hit_with).  Every test starts from
-// the ray's own t_max instead of the closest hit so far: a box beyond the closest hit then reports a hit the minimum
-// discards, where the loop would have had it rejected -- same winner, same t.
-//   flat:  SPREAD_CAP words, the pairs (ray << 16 | member); then 2 SPREAD_CAP words, t of each test (all ones: no hit);
-//          then SPREAD_CAP words, member << 16 | aux of each test   -- `rows`, whose queue of the cluster walk is done with
-//   slots: 64 x 8 bytes smallest t per ray, then 64 words largest key per ray   -- `list`, once the pairs are copied out
-constexpr int SPREAD_CAP = 256;
-static_assert(4 * SPREAD_CAP <= ITEM_CAP / 2, "pairs and results of the spread tests use the queue's words");
-static_assert(64 * 3 <= CAND_CAP * 32, "per-ray slots of the spread tests use the candidate lists' words");
 
 // Closest hit in [t_min, t_max] of one ray per lane against the boxes of the set; exact_ray(j, o, d, t_max, t) is the
 // reference's test of box j for the ray (o, d): on a hit it returns a non-negative number the caller wants back with
@@ -132,16 +111,7 @@ __device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d
     const uint32_t my_n = overflow ? 0u : cnt;
     // the candidates of the two-level walk come in no particular order: of two boxes hit at exactly the same t the
     // later one in the set wins, as it does when the reference tests them in order (see closest_hit_with)
-    // the lanes' counts numbered through the wave
-    uint32_t upto = my_n;  // inclusive prefix sum
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t below = (uint32_t)__shfl_up((int)upto, off);
-        if (lane >= off) upto += below;
-    }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
-    const uint32_t busiest = (uint32_t)wave_max_u32(my_n);
-    if (total > (uint32_t)SPREAD_CAP || busiest <= 1u || RT_SPREAD_BOX_TESTS == 0) {  // one round anyway, or too many for the words at hand
+    if (!spread_exact_tests(my_n, o, d, t_max, list, rows, lane, h, exact_ray)) {
         for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
             if (i < my_n) {
                 const int j = (int)list[i * 64 + lane];
@@ -150,50 +120,6 @@ __device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d
                 if (one.id >= 0 && (one.t < h.t || j > h.id)) h = one;
             }
         }
-    } else if (total != 0u) {
-        uint32_t* flat = rows;
-        uint64_t* res_t = (uint64_t*)(rows + SPREAD_CAP);
-        uint32_t* res_key = rows + 3 * SPREAD_CAP;
-        for (uint32_t i = 0; i < busiest; ++i)
-            if (i < my_n) flat[upto - my_n + i] = ((uint32_t)lane << 16) | (uint32_t)list[i * 64 + lane];
-        lds_wave_sync();
-        uint64_t* slot_t = (uint64_t*)list;
-        uint32_t* slot_key = (uint32_t*)list + 128;
-        slot_t[lane] = ~0ull;
-        slot_key[lane] = 0u;
-        lds_wave_sync();
-        for (uint32_t base = 0; base < total; base += 64u) {
-            const bool live = base + (uint32_t)lane < total;
-            const uint32_t pair = live ? flat[base + lane] : 0u;
-            const int ray = (int)(pair >> 16), j = (int)(pair & 0xFFFFu);
-            const d3 ro{lane_value_of(o.x, ray), lane_value_of(o.y, ray), lane_value_of(o.z, ray)};
-            const d3 rd{lane_value_of(d.x, ray), lane_value_of(d.y, ray), lane_value_of(d.z, ray)};
-            const double rt = lane_value_of(t_max, ray);
-            if (live) {
-                double t;
-                const int aux = exact_ray(j, ro, rd, rt, t);
-                const uint64_t bits = aux >= 0 ? (uint64_t)__double_as_longlong(t) : ~0ull;
-                res_t[base + lane] = bits;
-                res_key[base + lane] = ((uint32_t)j << 16) | (uint32_t)(aux & 0xFFFF);
-                if (aux >= 0) __hip_atomic_fetch_min(&slot_t[ray], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-        lds_wave_sync();
-        for (uint32_t base = 0; base < total; base += 64u) {
-            if (base + (uint32_t)lane < total) {
-                const int ray = (int)(flat[base + lane] >> 16);
-                const uint64_t bits = res_t[base + lane];
-                if (bits != ~0ull && bits == slot_t[ray])
-                    __hip_atomic_fetch_max(&slot_key[ray], res_key[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-        lds_wave_sync();
-        if (slot_t[lane] != ~0ull) {
-            h.t = __longlong_as_double((long long)slot_t[lane]);
-            h.id = (int32_t)(slot_key[lane] >> 16);
-            h.aux = (int32_t)(slot_key[lane] & 0xFFFFu);
-        }
-        lds_wave_sync();  // the lists' words are the caller's again
     }
     if (ballot(overflow) != 0ull) {
         if (overflow) {  // more candidates than slots, or a ray the float bound does not cover: every box in double

@@ -445,6 +445,13 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                     best.id = j;
                                     best.aux = id;
                                 }
+                            }, [&](int j, d3 ro, d3 rd, double t_max, double& t) -> int {  // the same for a ray of another lane
+#ifdef RT_SCENE_PROBE
+                                atomicAdd(&g_probe_total[1], 1ull);
+#endif
+                                const SphereExact se = set.spheres.exact[j];
+                                const Ray ray{ro, rd};
+                                return hit_sphere(d3{se.cx, se.cy, se.cz}, se.radius, ray, len2(rd), T_MIN, t_max, t) ? S.set_nodes[first_slot + j] : -1;
                             });
                             best_t = sh.t;
                             if (sh.id >= 0) {

@@ -3,6 +3,7 @@
 // candidates.  Shared by the sphere-list kernels (the whole world is one set) and the scene-graph kernels (a BVH
 // subtree that holds only spheres is one set).
 #pragma once
+#include <type_traits>
 
 #include "rt_device_common.h"
 #include "rt_internal.h"
@@ -288,15 +289,102 @@ __device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3
     h.id = j;
 }
 
+// Double-precision tests handed round the wave.  After the screens a few lanes hold several candidates each and most
+// hold none (a set of boxes inside a scene graph: ~45 candidates on ~17 rays per visit of the wave, the busiest lane 5 or 6; a
+// dense set of spheres: ~80 on 5 rays), and
+// a loop in which every lane works through its own list runs as long as the busiest lane.  Here the (ray, member) pairs are
+// numbered through the wave (prefix sum of the lanes' counts) and tested 64 at a time, one per lane, WHICHEVER lane the
+// ray belongs to: the ray's origin, direction and t_max arrive by lane permutation.  Results meet per ray in LDS: the
+// smallest t by a 64-bit unsigned minimum on its bit pattern (t >= t_min > 0: the patterns order like the values), then,
+// among the tests that reached that t, the largest member index -- "t smaller, or equal and index larger", the rule of
+// the per-lane loop below, which is the reference's own order of testing (see closest_hit_with).  Every test starts from
+// the ray's own t_max instead of the closest hit so far: a member beyond the closest hit then reports a hit the minimum
+// discards, where the loop would have had it rejected -- same winner, same t.
+//   flat:  SPREAD_CAP words, the pairs (ray << 16 | member); then 2 SPREAD_CAP words, t of each test (all ones: no hit);
+//          then SPREAD_CAP words, member << 16 | aux of each test   -- `rows`, whose queue of the cluster walk is done with
+//   slots: 64 x 8 bytes smallest t per ray, then 64 words largest key per ray   -- `list`, once the pairs are copied out
+constexpr int SPREAD_CAP = 256;
+static_assert(4 * SPREAD_CAP <= ITEM_CAP / 2, "pairs and results of the spread tests use the queue's words");
+static_assert(64 * 3 <= CAND_CAP * 32, "per-ray slots of the spread tests use the candidate lists' words");
+
+#ifndef RT_SPREAD_EXACT_TESTS
+#define RT_SPREAD_EXACT_TESTS 1
+#endif
+// my_n = this lane's candidates (list[i * 64 + lane], i < my_n); exact_ray(j, o, d, t_max, t): the reference's test of
+// member j for the ray (o, d) -- on a hit a non-negative number the caller wants back with the winner (< 65536) and t
+// (<= t_max), otherwise a negative number.  Returns false, with nothing done, when the per-lane loop is as good (no lane
+// has two candidates) or the pairs do not fit; otherwise h holds the winner of the lanes that have one.  All 64 lanes
+// must call it; `list` and `rows` are overwritten.
+template <class ExactRayFn>
+__device__ __forceinline__ bool spread_exact_tests(uint32_t my_n, d3 o, d3 d, double t_max, uint16_t* list, uint32_t* rows, int lane,
+                                                   SetHit& h, ExactRayFn exact_ray) {
+    uint32_t upto = my_n;  // inclusive prefix sum: the lanes' counts numbered through the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t below = (uint32_t)__shfl_up((int)upto, off);
+        if (lane >= off) upto += below;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+    const uint32_t busiest = wave_max_u32(my_n);
+    if (RT_SPREAD_EXACT_TESTS == 0 || total > (uint32_t)SPREAD_CAP || busiest <= 1u) return false;
+    uint32_t* flat = rows;
+    uint64_t* res_t = (uint64_t*)(rows + SPREAD_CAP);
+    uint32_t* res_key = rows + 3 * SPREAD_CAP;
+    for (uint32_t i = 0; i < busiest; ++i)
+        if (i < my_n) flat[upto - my_n + i] = ((uint32_t)lane << 16) | (uint32_t)list[i * 64 + lane];
+    lds_wave_sync();
+    uint64_t* slot_t = (uint64_t*)list;
+    uint32_t* slot_key = (uint32_t*)list + 128;
+    slot_t[lane] = ~0ull;
+    slot_key[lane] = 0u;
+    lds_wave_sync();
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const bool live = base + (uint32_t)lane < total;
+        const uint32_t pair = live ? flat[base + lane] : 0u;
+        const int ray = (int)(pair >> 16), j = (int)(pair & 0xFFFFu);
+        const d3 ro{lane_value_of(o.x, ray), lane_value_of(o.y, ray), lane_value_of(o.z, ray)};
+        const d3 rd{lane_value_of(d.x, ray), lane_value_of(d.y, ray), lane_value_of(d.z, ray)};
+        const double rt = lane_value_of(t_max, ray);
+        if (live) {
+            double t;
+            const int aux = exact_ray(j, ro, rd, rt, t);
+            const uint64_t bits = aux >= 0 ? (uint64_t)__double_as_longlong(t) : ~0ull;
+            res_t[base + lane] = bits;
+            res_key[base + lane] = ((uint32_t)j << 16) | (uint32_t)(aux & 0xFFFF);
+            if (aux >= 0) __hip_atomic_fetch_min(&slot_t[ray], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    lds_wave_sync();
+    for (uint32_t base = 0; base < total; base += 64u) {
+        if (base + (uint32_t)lane < total) {
+            const int ray = (int)(flat[base + lane] >> 16);
+            const uint64_t bits = res_t[base + lane];
+            if (bits != ~0ull && bits == slot_t[ray])
+                __hip_atomic_fetch_max(&slot_key[ray], res_key[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    lds_wave_sync();
+    if (slot_t[lane] != ~0ull) {
+        h.t = __longlong_as_double((long long)slot_t[lane]);
+        h.id = (int32_t)(slot_key[lane] >> 16);
+        h.aux = (int32_t)(slot_key[lane] & 0xFFFFu);
+    }
+    lds_wave_sync();  // the words are the caller's again
+    return true;
+}
+
 // Closest hit in [t_min, t_max] of one ray per lane against the whole set; id = -1 if there is none.  Must be called
 // by all 64 lanes of the wave (wave-level loops); lanes with on == false take no part in the result.
 // `list` = this wave's CAND_CAP*64 uint16 slots in LDS, `rows` = its ROW_WORDS*64 words.
 // exact(j, h) is the double-precision test of member j: it lowers h.t and sets h.id = j if j is hit in [t_min, h.t].
 // The screening image holds, per member, a sphere that the member lies inside.
-template <class ExactFn>
+// exact_ray: the test in the form spread_exact_tests wants, or NoSpread{} (every lane works through its own candidates:
+// the sphere-list kernels, whose lanes all hold a few).
+struct NoSpread {};
+template <class ExactFn, class ExactRayFn = NoSpread>
 __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, d3 d, double t_max, bool on, bool exact_only,
                                                    uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
-                                                   ProbeClock& pc, ExactFn exact) {
+                                                   ProbeClock& pc, ExactFn exact, ExactRayFn exact_ray = {}) {
     const double a = len2(d);
     SetHit h{t_max, -1};
 
@@ -380,12 +468,16 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     // The reference tests the members in list order and accepts a root equal to the closest so far, so of two members
     // hit at exactly the same t the later one wins.  The candidates of the two-level walk come in no particular order:
     // the same rule stated on the indices gives the same winner for any order.
-    for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
-        if (i < my_n) {
-            const int j = (int)list[i * 64 + lane];
-            SetHit one{h.t, -1};
-            exact(j, one);
-            if (one.id >= 0 && (one.t < h.t || j > h.id)) h = one;
+    bool spread = false;
+    if constexpr (!std::is_same<ExactRayFn, NoSpread>::value) spread = spread_exact_tests(my_n, o, d, t_max, list, rows, lane, h, exact_ray);
+    if (!spread) {
+        for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
+            if (i < my_n) {
+                const int j = (int)list[i * 64 + lane];
+                SetHit one{h.t, -1};
+                exact(j, one);
+                if (one.id >= 0 && (one.t < h.t || j > h.id)) h = one;
+            }
         }
     }
     if (ballot(overflow) != 0ull) {
