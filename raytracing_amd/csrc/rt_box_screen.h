@@ -111,7 +111,7 @@ __device__ __forceinline__ SetHit closest_box_hit(const BoxSetDev& B, d3 o, d3 d
     const uint32_t my_n = overflow ? 0u : cnt;
     // the candidates of the two-level walk come in no particular order: of two boxes hit at exactly the same t the
     // later one in the set wins, as it does when the reference tests them in order (see closest_hit_with)
-    if (!spread_exact_tests(my_n, o, d, t_max, list, rows, lane, h, exact_ray)) {
+    if (!spread_exact_tests(my_n, o, d, t_max, 0.0, list, rows, lane, h, [&](int j, d3 ro, d3 rd, double rt, double, double& t) { return exact_ray(j, ro, rd, rt, t); })) {
         for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
             if (i < my_n) {
                 const int j = (int)list[i * 64 + lane];

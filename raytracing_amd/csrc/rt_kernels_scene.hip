@@ -445,7 +445,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                     best.id = j;
                                     best.aux = id;
                                 }
-                            }, [&](int j, d3 ro, d3 rd, double t_max, double& t) -> int {  // the same for a ray of another lane
+                            }, [&](int j, d3 ro, d3 rd, double t_max, double, double& t) -> int {  // the same for a ray of another lane
 #ifdef RT_SCENE_PROBE
                                 atomicAdd(&g_probe_total[1], 1ull);
 #endif

@@ -310,14 +310,14 @@ static_assert(64 * 3 <= CAND_CAP * 32, "per-ray slots of the spread tests use th
 #ifndef RT_SPREAD_EXACT_TESTS
 #define RT_SPREAD_EXACT_TESTS 1
 #endif
-// my_n = this lane's candidates (list[i * 64 + lane], i < my_n); exact_ray(j, o, d, t_max, t): the reference's test of
-// member j for the ray (o, d) -- on a hit a non-negative number the caller wants back with the winner (< 65536) and t
+// my_n = this lane's candidates (list[i * 64 + lane], i < my_n); exact_ray(j, o, d, t_max, time, t): the reference's test
+// of member j for the ray (o, d, time) -- on a hit a non-negative number the caller wants back with the winner (< 65536) and t
 // (<= t_max), otherwise a negative number.  Returns false, with nothing done, when the per-lane loop is as good (no lane
 // has two candidates) or the pairs do not fit; otherwise h holds the winner of the lanes that have one.  All 64 lanes
 // must call it; `list` and `rows` are overwritten.
 template <class ExactRayFn>
-__device__ __forceinline__ bool spread_exact_tests(uint32_t my_n, d3 o, d3 d, double t_max, uint16_t* list, uint32_t* rows, int lane,
-                                                   SetHit& h, ExactRayFn exact_ray) {
+__device__ __forceinline__ bool spread_exact_tests(uint32_t my_n, d3 o, d3 d, double t_max, double ray_time, uint16_t* list, uint32_t* rows,
+                                                   int lane, SetHit& h, ExactRayFn exact_ray) {
     uint32_t upto = my_n;  // inclusive prefix sum: the lanes' counts numbered through the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -344,10 +344,10 @@ __device__ __forceinline__ bool spread_exact_tests(uint32_t my_n, d3 o, d3 d, do
         const int ray = (int)(pair >> 16), j = (int)(pair & 0xFFFFu);
         const d3 ro{lane_value_of(o.x, ray), lane_value_of(o.y, ray), lane_value_of(o.z, ray)};
         const d3 rd{lane_value_of(d.x, ray), lane_value_of(d.y, ray), lane_value_of(d.z, ray)};
-        const double rt = lane_value_of(t_max, ray);
+        const double rt = lane_value_of(t_max, ray), rtm = lane_value_of(ray_time, ray);
         if (live) {
             double t;
-            const int aux = exact_ray(j, ro, rd, rt, t);
+            const int aux = exact_ray(j, ro, rd, rt, rtm, t);
             const uint64_t bits = aux >= 0 ? (uint64_t)__double_as_longlong(t) : ~0ull;
             res_t[base + lane] = bits;
             res_key[base + lane] = ((uint32_t)j << 16) | (uint32_t)(aux & 0xFFFF);
@@ -384,7 +384,7 @@ struct NoSpread {};
 template <class ExactFn, class ExactRayFn = NoSpread>
 __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, d3 d, double t_max, bool on, bool exact_only,
                                                    uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
-                                                   ProbeClock& pc, ExactFn exact, ExactRayFn exact_ray = {}) {
+                                                   ProbeClock& pc, ExactFn exact, ExactRayFn exact_ray = {}, double ray_time = 0.0) {
     const double a = len2(d);
     SetHit h{t_max, -1};
 
@@ -469,7 +469,7 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     // hit at exactly the same t the later one wins.  The candidates of the two-level walk come in no particular order:
     // the same rule stated on the indices gives the same winner for any order.
     bool spread = false;
-    if constexpr (!std::is_same<ExactRayFn, NoSpread>::value) spread = spread_exact_tests(my_n, o, d, t_max, list, rows, lane, h, exact_ray);
+    if constexpr (!std::is_same<ExactRayFn, NoSpread>::value) spread = spread_exact_tests(my_n, o, d, t_max, ray_time, list, rows, lane, h, exact_ray);
     if (!spread) {
         for (uint32_t i = 0; ballot(i < my_n) != 0ull; ++i) {
             if (i < my_n) {
@@ -490,15 +490,32 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
     return h;
 }
 
-// The set's members are its spheres themselves (sphere-list kernels).
+// The set's members are its spheres themselves (sphere-list kernels).  RT_SPREAD_LIST_TESTS: their double-precision tests
+// handed round the wave as well.
+#ifndef RT_SPREAD_LIST_TESTS
+#define RT_SPREAD_LIST_TESTS 0
+#endif
 template <bool TIMED>
 __device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d, double tm, double t_max, bool on, bool exact_only,
                                               uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
                                               ProbeClock& pc) {
     const double a = len2(d);
     const double t_min = 0.001;  // B1/RayTracing.cpp:17
+#if RT_SPREAD_LIST_TESTS
+    return closest_hit_with(
+        S, o, d, t_max, on, exact_only, list, rows, lane, overflow_count, pc,
+        [&](int j, SetHit& h) { exact_one<TIMED>(S, j, o, d, a, tm, t_min, h); },
+        [&](int j, d3 ro, d3 rd, double rt, double rtm, double& t) -> int {
+            SetHit one{rt, -1};
+            exact_one<TIMED>(S, j, ro, rd, len2(rd), rtm, t_min, one);
+            t = one.t;
+            return one.id >= 0 ? 0 : -1;
+        },
+        tm);
+#else
     return closest_hit_with(S, o, d, t_max, on, exact_only, list, rows, lane, overflow_count, pc,
                             [&](int j, SetHit& h) { exact_one<TIMED>(S, j, o, d, a, tm, t_min, h); });
+#endif
 }
 
 }  // namespace rtd
