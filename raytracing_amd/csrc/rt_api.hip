@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -299,6 +300,7 @@ struct SphereSetWalk {
     std::vector<int>& tops;
     bool graph_leaves;  // leaves of a leaf set inside a graph: static spheres of any material (shading goes by node id)
                         // and boxes whose sides are those box::box derives; moving spheres disqualify the subtree
+    bool saw_bvh = false;
     struct Box {
         double lo[3], hi[3];
     };
@@ -366,6 +368,7 @@ struct SphereSetWalk {
         }
         if (n.kind == RT_NODE_BVH) {
             Box l, r;
+            saw_bvh = true;
             if (!walk(n.child0, top, l) || !walk(n.child1, top, r)) return false;
             box = join(l, r);
             for (int k = 0; k < 3; ++k)
@@ -390,10 +393,32 @@ struct SphereSetWalk {
         return false;
     }
 };
+// Two leaves of the same shape in the same place.  Between the leaves of a tree the flat form settles a hit at exactly
+// the same t in favour of the later leaf, as hittable_list::hit does and as bvh_node::hit does for the two children of
+// one node; but a node further up tests its box against the closest hit so far first and rejects it when the ray
+// enters the box exactly there (aabb::hit: t_max <= t_min, B2/aabb.h:24-41), so of two coincident leaves in different
+// subtrees the reference keeps the EARLIER one.  For rays in general position such ties do not happen; a world that holds
+// the same leaf twice makes them happen for every ray that hits it, so such a tree keeps its walk.
+static bool has_coincident_leaves(const rt_scene_desc* sc, const std::vector<int>& prims) {
+    std::vector<std::array<double, 10>> keys;
+    keys.reserve(prims.size());
+    for (int id : prims) {
+        const rt_node& n = sc->nodes[id];
+        std::array<double, 10> k{};
+        k[0] = (double)n.kind;
+        const int used = n.kind == RT_NODE_SPHERE ? 4 : (n.kind == RT_NODE_BOX ? 6 : 9);
+        for (int i = 0; i < used; ++i) k[1 + i] = n.p[i];
+        keys.push_back(k);
+    }
+    std::sort(keys.begin(), keys.end());
+    return std::adjacent_find(keys.begin(), keys.end()) != keys.end();
+}
+
 static bool collect_sphere_set(const rt_scene_desc* sc, int max_spheres, std::vector<int>& prims, std::vector<int>& tops) {
     SphereSetWalk w{sc, max_spheres, prims, tops, false};
     SphereSetWalk::Box box;
-    return w.walk(sc->root, -1, box);
+    if (!w.walk(sc->root, -1, box)) return false;
+    return !(w.saw_bvh && has_coincident_leaves(sc, prims));
 }
 
 static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
@@ -868,6 +893,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true};
             SphereSetWalk::Box box;
             if (!w.walk(idx, i, box) || (int)prims.size() < ctx->subtree_set_min) continue;
+            if (has_coincident_leaves(sc, prims)) continue;
             std::vector<int> spheres, boxes, sphere_order, box_order;  // order = position in the tree's depth-first walk
             double coord_max = 0.0;
             for (size_t k = 0; k < prims.size(); ++k) {

@@ -303,7 +303,10 @@ __device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3
 //   flat:  SPREAD_CAP words, the pairs (ray << 16 | member); then 2 SPREAD_CAP words, t of each test (all ones: no hit);
 //          then SPREAD_CAP words, member << 16 | aux of each test   -- `rows`, whose queue of the cluster walk is done with
 //   slots: 64 x 8 bytes smallest t per ray, then 64 words largest key per ray   -- `list`, once the pairs are copied out
-constexpr int SPREAD_CAP = 256;
+#ifndef RT_SPREAD_CAP
+#define RT_SPREAD_CAP 256
+#endif
+constexpr int SPREAD_CAP = RT_SPREAD_CAP;
 static_assert(4 * SPREAD_CAP <= ITEM_CAP / 2, "pairs and results of the spread tests use the queue's words");
 static_assert(64 * 3 <= CAND_CAP * 32, "per-ray slots of the spread tests use the candidate lists' words");
 

@@ -273,3 +273,80 @@ def test_sphere_and_box_of_one_leaf_set_hit_at_the_same_t(sphere_first, monkeypa
             got, st = c.render(degenerate(lib.camera), p)
         assert st["rays"] == ost["rays"]
         assert np.array_equal(got, want), (sphere_first, set_min, got[0, 0], want[0, 0])
+
+
+def _straight_down(make):
+    """Camera with a zero-sized viewport: whatever the pixel jitter, origin (0.5, 5, 0.5), direction (0, -1, 0)."""
+    cam = make((0.5, 5, 0.5), (0.5, 0, 0.5), (0, 0, 1), 40.0, 1.0, 0.0, 1.0, 0.0, 1.0)
+    for k in range(3):
+        cam.horizontal[k] = cam.vertical[k] = 0.0
+        cam.lower_left_corner[k] = (0.5, 4.0, 0.5)[k]
+    return cam
+
+
+def _lamps(kind, shapes):
+    """A WorldBuilder and one lamp leaf per entry of shapes (its colour the entry's index into COLOURS)."""
+    from tests.test_fuzz_worlds import WorldBuilder
+    w = WorldBuilder(np.random.default_rng(0))
+    leaves = []
+    for i, shape in enumerate(shapes):
+        w.mat.append((abi.RT_MAT_DIFFUSE_LIGHT, w.solid(COLOURS[i]), (0, 0, 0), 0.0))
+        lamp = len(w.mat) - 1
+        w.material = lambda allow_light=True, lamp=lamp: lamp
+        leaves.append(w.box(*shape) if kind == "boxes" else w.sphere(*shape))
+    return w, leaves
+
+
+def _join(w, a, b):
+    (l, lb), (r, rb) = a, b
+    lo, hi = np.minimum(lb[0], rb[0]), np.maximum(lb[1], rb[1])
+    return (w.node(abi.RT_NODE_BVH, -1, l, r, p=(*lo, *hi)), (lo, hi))
+
+
+COLOURS = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (1.0, 1.0, 0.0)]
+
+
+def _render_as_set_and_as_tree(scene, monkeypatch, what):
+    p = abi.render_params(4, 4, 3, 50, seed=1)
+    _, fixed, ost = ob.render(scene, _straight_down(ob.camera), p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=2)
+    want = fixed.astype(np.float64) / FRAC
+    for set_min in (2, 1000):   # the subtree as a leaf set (if it qualifies); the subtree walked through the stack
+        monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+        with lib.Context(0) as c:
+            c.upload(scene)
+            got, st = c.render(_straight_down(lib.camera), p)
+        assert st["rays"] == ost["rays"]
+        assert np.array_equal(got, want), (what, set_min, got[0, 0], want[0, 0])
+    return want
+
+
+@pytest.mark.parametrize("kind", ["boxes", "spheres"])
+@pytest.mark.parametrize("larger_first", [False, True])
+def test_two_leaves_of_one_node_hit_at_the_same_t(kind, larger_first, monkeypatch):
+    """Two lamps of different size under one bvh_node whose tops meet the ray at exactly t = 4 (boxes with their top faces
+    in one plane; a sphere of radius 1 inside one of radius 2, touching at the top): the right child is tested with the
+    left child's t as its limit and accepts an equal root (B2/bvh.h:99-104), so the later leaf wins.  As a leaf set every
+    lane holds both candidates: their double-precision tests are handed round the wave and merged per ray -- smallest
+    t, then largest member."""
+    shapes = [((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((-1.0, 0.5, -1.0), (2.0, 1.0, 2.0))] if kind == "boxes" else \
+             [((0.5, 0.0, 0.5), 1.0), ((0.5, -1.0, 0.5), 2.0)]
+    w, leaves = _lamps(kind, shapes)
+    first, second = (1, 0) if larger_first else (0, 1)
+    scene = w.finish([_join(w, leaves[first], leaves[second])], abi.RT_SKY_BACKGROUND)
+    want = _render_as_set_and_as_tree(scene, monkeypatch, (kind, larger_first))
+    assert np.array_equal(want[0, 0], 3.0 * np.array(COLOURS[second]))  # three samples of the later leaf's colour
+
+
+@pytest.mark.parametrize("kind", ["boxes", "spheres"])
+def test_the_same_leaf_four_times_in_one_tree(kind, monkeypatch):
+    """Four identical lamps of different colours in a tree of depth two (depth-first order 2, 0, 3, 1), every ray hitting
+    all four at exactly t = 4.  Within the left subtree the later leaf (0) takes the hit from the earlier; the right
+    subtree is never entered, because its box is tested against the closest hit so far first and aabb::hit rejects a ray
+    that enters the box exactly there (t_max <= t_min, B2/aabb.h:24-41): the reference's answer is leaf 0, not the last
+    leaf.  A flat form of the tree cannot know that, so trees that hold the same leaf twice keep their walk."""
+    shape = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) if kind == "boxes" else ((0.5, 0.0, 0.5), 1.0)
+    w, leaves = _lamps(kind, [shape] * 4)
+    tree = _join(w, _join(w, leaves[2], leaves[0]), _join(w, leaves[3], leaves[1]))
+    scene = w.finish([tree], abi.RT_SKY_BACKGROUND)
+    want = _render_as_set_and_as_tree(scene, monkeypatch, kind)
+    assert np.array_equal(want[0, 0], 3.0 * np.array(COLOURS[0]))

@@ -88,6 +88,14 @@ def test_ray_through_more_clusters_than_a_lane_holds(monkeypatch):
     assert out["two-level"][1]["overflow_rays"] > 0
 
 
+def test_more_clusters_than_lanes(monkeypatch):
+    """1297 spheres = 82 clusters: a wave with few rays left (the end of every launch) walks the clusters' boxes one box
+    per lane, 64 clusters at a time, so this world takes two turns."""
+    scene = grid_world(n_side=36)
+    render_all_ways(monkeypatch, scene, ((20, 5, 16), (0, 0, 0), (0, 1, 0), 45.0, 1.5, 0.05, 20.0),
+                    abi.render_params(60, 40, 3, 50, seed=12), (60, 40))
+
+
 @pytest.mark.parametrize("scale", [1.0e-3, 1.0e3, 1.0e7])
 def test_scaled_worlds(monkeypatch, scale):
     """The margins scale with the world; beyond 1e6 the set has no two-level form and the flat walk serves it."""
