@@ -301,6 +301,8 @@ struct SphereSetWalk {
     bool graph_leaves;  // leaves of a leaf set inside a graph: static spheres of any material (shading goes by node id)
                         // and boxes whose sides are those box::box derives; moving spheres disqualify the subtree
     bool saw_bvh = false;
+    std::vector<int> parent_of;  // per leaf: the bvh_node (or list) it hangs under
+    int parent = -1;
     struct Box {
         double lo[3], hi[3];
     };
@@ -354,6 +356,7 @@ struct SphereSetWalk {
             }
             prims.push_back(idx);
             tops.push_back(top);
+            parent_of.push_back(parent);
             return true;
         }
         if (graph_leaves && n.kind == RT_NODE_BOX) {  // box::bounding_box, B2/box.h:20-23
@@ -364,12 +367,17 @@ struct SphereSetWalk {
             }
             prims.push_back(idx);
             tops.push_back(top);
+            parent_of.push_back(parent);
             return true;
         }
         if (n.kind == RT_NODE_BVH) {
             Box l, r;
             saw_bvh = true;
-            if (!walk(n.child0, top, l) || !walk(n.child1, top, r)) return false;
+            const int above = parent;
+            parent = idx;
+            const bool both = walk(n.child0, top, l) && walk(n.child1, top, r);
+            parent = above;
+            if (!both) return false;
             box = join(l, r);
             for (int k = 0; k < 3; ++k)
                 if (!(n.p[k] <= box.lo[k] && n.p[3 + k] >= box.hi[k])) return false;  // this node could cull a leaf
@@ -383,6 +391,7 @@ struct SphereSetWalk {
             bool first = true;
             for (int i = 0; i < n.child1; ++i) {
                 Box c;
+                parent = idx;
                 if (!walk(sc->children[n.child0 + i], idx == sc->root ? i : top, c)) return false;
                 box = first ? c : join(box, c);
                 first = false;
@@ -398,27 +407,37 @@ struct SphereSetWalk {
 // one node; but a node further up tests its box against the closest hit so far first and rejects it when the ray
 // enters the box exactly there (aabb::hit: t_max <= t_min, B2/aabb.h:24-41), so of two coincident leaves in different
 // subtrees the reference keeps the EARLIER one.  For rays in general position such ties do not happen; a world that holds
-// the same leaf twice makes them happen for every ray that hits it, so such a tree keeps its walk.
-static bool has_coincident_leaves(const rt_scene_desc* sc, const std::vector<int>& prims) {
-    std::vector<std::array<double, 10>> keys;
+// the same leaf twice makes them happen for every ray that hits it, so such a tree keeps its walk -- unless the two are
+// the children of one node (the reference's own trees hold those: bvh_node's constructor makes the last object of an
+// odd span both children of its node, B2/bvh.h:65-66) or neighbours in a list, where the later one wins in both forms.
+static bool has_coincident_leaves(const rt_scene_desc* sc, const std::vector<int>& prims, const std::vector<int>& parent_of) {
+    struct Key {
+        std::array<double, 10> k;
+        int parent;
+        bool operator<(const Key& o) const { return k < o.k; }
+    };
+    std::vector<Key> keys;
     keys.reserve(prims.size());
-    for (int id : prims) {
-        const rt_node& n = sc->nodes[id];
-        std::array<double, 10> k{};
-        k[0] = (double)n.kind;
+    for (size_t i = 0; i < prims.size(); ++i) {
+        const rt_node& n = sc->nodes[prims[i]];
+        Key key{};
+        key.k[0] = (double)n.kind;
         const int used = n.kind == RT_NODE_SPHERE ? 4 : (n.kind == RT_NODE_BOX ? 6 : 9);
-        for (int i = 0; i < used; ++i) k[1 + i] = n.p[i];
-        keys.push_back(k);
+        for (int c = 0; c < used; ++c) key.k[1 + c] = n.p[c];
+        key.parent = parent_of[i];
+        keys.push_back(key);
     }
     std::sort(keys.begin(), keys.end());
-    return std::adjacent_find(keys.begin(), keys.end()) != keys.end();
+    for (size_t i = 0; i + 1 < keys.size(); ++i)
+        if (keys[i].k == keys[i + 1].k && keys[i].parent != keys[i + 1].parent) return true;
+    return false;
 }
 
 static bool collect_sphere_set(const rt_scene_desc* sc, int max_spheres, std::vector<int>& prims, std::vector<int>& tops) {
     SphereSetWalk w{sc, max_spheres, prims, tops, false};
     SphereSetWalk::Box box;
     if (!w.walk(sc->root, -1, box)) return false;
-    return !(w.saw_bvh && has_coincident_leaves(sc, prims));
+    return !(w.saw_bvh && has_coincident_leaves(sc, prims, w.parent_of));
 }
 
 static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
@@ -893,7 +912,7 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             SphereSetWalk w{sc, ctx->subtree_set_max, prims, tops, true};
             SphereSetWalk::Box box;
             if (!w.walk(idx, i, box) || (int)prims.size() < ctx->subtree_set_min) continue;
-            if (has_coincident_leaves(sc, prims)) continue;
+            if (has_coincident_leaves(sc, prims, w.parent_of)) continue;
             std::vector<int> spheres, boxes, sphere_order, box_order;  // order = position in the tree's depth-first walk
             double coord_max = 0.0;
             for (size_t k = 0; k < prims.size(); ++k) {
