@@ -893,6 +893,9 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
 #endif
 // Philox blocks of the rejection loops computed by the whole wave (philox_blocks_for_lanes)?  Measured on these
 // kernels, which wait on dependent loads rather than on vector issue: no gain (final scene -1 %, Cornell box +3 %).
+#ifndef RT_PARK_PATH_STATE
+#define RT_PARK_PATH_STATE 1
+#endif
 #ifndef RT_SCENE_WAVE_BLOCKS
 #define RT_SCENE_WAVE_BLOCKS 0
 #endif
@@ -903,6 +906,10 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     // variant that needs neither is not held back by LDS: 4 workgroups of 40 KB would not fit a CU's 160 KB)
     constexpr int STACK_WORDS = (F & F_STACK) != 0 ? STACK_CAP * 64 : ((F & F_SET) != 0 ? CAND_CAP * 32 + ROW_WORDS * 64 : 64);
     __shared__ uint32_t s_stack[4][STACK_WORDS];
+#if RT_PARK_PATH_STATE
+    constexpr bool PARK = MIN_WAVES >= 3 && (F & F_SET) != 0 && (F & F_STACK) == 0;  // the variant that spills most and has the LDS to spare
+    __shared__ double s_park[4][PARK ? 6 : 1][64];
+#endif
     // The camera (21 doubles) is needed once per sample; read from the kernel arguments it would sit in 42 scalar
     // registers for the whole kernel and push hot values out.  One copy per wave in LDS, read back where it is used.
     __shared__ CameraDev s_cam[4];
@@ -952,7 +959,29 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         const bool on = active;
         const RngCtx g{w.pixel, (uint32_t)w.s_cur, 1u + bounce, A.key0, A.key1};
         PROBE_MARK(PS_REFILL);
+#if RT_PARK_PATH_STATE
+        // What the traversal does not touch -- the path's throughput and the item's sums, 12 registers -- waits in LDS
+        // meanwhile: the traversal is where registers run out, and what the compiler spills goes to scratch memory.
+        if constexpr (PARK) {
+            volatile double* pk = s_park[threadIdx.x >> 6][0] + lane;
+            pk[0 * 64] = T.x;
+            pk[1 * 64] = T.y;
+            pk[2 * 64] = T.z;
+            pk[3 * 64] = __longlong_as_double((long long)w.fx);
+            pk[4 * 64] = __longlong_as_double((long long)w.fy);
+            pk[5 * 64] = __longlong_as_double((long long)w.fz);
+        }
+#endif
         const Hit h = trace<F>(S, r, tm, on, A.exact_only != 0, stack, lane, g);
+#if RT_PARK_PATH_STATE
+        if constexpr (PARK) {
+            volatile double* pk = s_park[threadIdx.x >> 6][0] + lane;
+            T = d3{pk[0 * 64], pk[1 * 64], pk[2 * 64]};
+            w.fx = (int64_t)__double_as_longlong(pk[3 * 64]);
+            w.fy = (int64_t)__double_as_longlong(pk[4 * 64]);
+            w.fz = (int64_t)__double_as_longlong(pk[5 * 64]);
+        }
+#endif
 #ifdef RT_SCENE_PROBE
         probe_t = clock64();  // trace() accounts for its own sections
 #endif
