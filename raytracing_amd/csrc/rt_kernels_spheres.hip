@@ -43,6 +43,9 @@ namespace rtd {
 #endif
 // The book-2 variant also fits 4 waves/SIMD (6 spilled registers outside the loop; measured 3 % faster than at 3
 // waves) now that the checker texture evaluates no sin() inline.
+#ifndef RT_ARGS_FROM_MEMORY
+#define RT_ARGS_FROM_MEMORY 1
+#endif
 #ifndef RT_TIMED_WAVE_BLOCKS
 #define RT_TIMED_WAVE_BLOCKS 0
 #endif
@@ -61,7 +64,8 @@ __device__ __forceinline__ d3 sphere_world_texture(const SphereListDev& S, int t
 }
 
 template <bool TIMED>
-__global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A) {
+__global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A_in) {
+    const RenderArgs& A = A_in;
     __shared__ uint16_t s_list[4][CAND_CAP * 64];
     __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
@@ -104,7 +108,19 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
 
     ProbeClock pc;
     pc.start();
+#if RT_ARGS_FROM_MEMORY
+    // The arguments fill ~70 scalar registers; held across the loop they are spilled to lanes of a vector register and
+    // every reload is a vector instruction.  Read through a pointer the compiler cannot see through, each field is a
+    // scalar load where the trip uses it and nothing but the pointer lives from one trip to the next.
+    typedef __attribute__((address_space(4))) const RenderArgs KernArgs;
+    KernArgs* args_in_memory = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
     for (;;) {
+#if RT_ARGS_FROM_MEMORY
+        asm volatile("" : "+s"(args_in_memory));
+        const RenderArgs& A = *(const RenderArgs*)args_in_memory;  // (the loads stay scalar: the address space is inferred)
+        const SphereListDev& S = A.scene;
+#endif
         // ---- refill: finish items, take new ones, start the next sample
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
         {   // the lanes that start a sample
