@@ -132,8 +132,9 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                 camera_ray_for_lanes<TIMED, RT_COOP_CAMERA != 0>(start, cam, A.width_m1, A.height_m1, i, j, w.pixel, (uint32_t)w.s_cur, A.key0,
                                                                  A.key1, lane, nullptr, o, d, tm);
             } else if (start) {  // (the book-2 variant is at its register limit: every lane computes its own blocks, in the branch)
-                const int i = (int)(w.pixel % (uint32_t)A.width);
-                const int j = A.height - 1 - (int)(w.pixel / (uint32_t)A.width);
+                const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
+                const int i = (int)(w.pixel - row * (uint32_t)A.width);
+                const int j = A.height - 1 - (int)row;
                 camera_ray_for_lanes<TIMED, false>(true, cam, A.width_m1, A.height_m1, i, j, w.pixel, (uint32_t)w.s_cur, A.key0, A.key1, lane,
                                                    nullptr, o, d, tm);
             }
