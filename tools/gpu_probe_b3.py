@@ -1,3 +1,5 @@
+"""Kernel time of the Rest-Of-Your-Life Cornell box with light sampling at 600x600 and a few sample counts (used by
+tools/ab_all.sh)."""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 from raytracing_amd import abi, lib
