@@ -853,8 +853,10 @@ __device__ __forceinline__ d3 shape_random(const SceneNode& n, d3 origin, uint32
     const double r1 = u01(w2), r2 = u01(w3);  // random_to_sphere
     const double z = 1 + r2 * (sqrt(1 - n.p[3] * n.p[3] / distance_squared) - 1);
     const double phi = 2 * PI_D * r1;
-    const double x = cos(phi) * sqrt(1 - z * z);
-    const double y = sin(phi) * sqrt(1 - z * z);
+    double sin_phi, cos_phi;  // one argument reduction for both; the device library's sincos returns what its sin and cos
+    sincos(phi, &sin_phi, &cos_phi);  // return (compared over 1.3e8 rays of config 5: not one sum differs)
+    const double x = cos_phi * sqrt(1 - z * z);
+    const double y = sin_phi * sqrt(1 - z * z);
     return onb_local(uvw, d3{x, y, z});
 }
 // One lambertian bounce of the book's ray_color: direction from the 50/50 mixture of the light density and the
@@ -869,8 +871,10 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
         const double r1 = u01(ph.z), r2 = u01(ph.w);
         const double z = sqrt(1 - r2);
         const double phi = 2 * PI_D * r1;
-        const double x = cos(phi) * sqrt(r2);
-        const double y = sin(phi) * sqrt(r2);
+        double sin_phi, cos_phi;
+        sincos(phi, &sin_phi, &cos_phi);
+        const double x = cos_phi * sqrt(r2);
+        const double y = sin_phi * sqrt(r2);
         dir = onb_local(uvw, d3{x, y, z});
     }
     const d3 ud = unit_vector(dir);
