@@ -930,6 +930,38 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
             int rc = spheres.empty() ? RT_OK : build_sphere_set(ctx, sc, spheres, false, true, sd.spheres, lo, hi);
             if (rc == RT_OK && !boxes.empty()) rc = build_box_set(ctx, sc, boxes, cover, sd.boxes);
             if (rc != RT_OK) return rc;
+            {   // the subtree in depth-first order with skip links (ReplayNode)
+                std::vector<ReplayNode> replay;
+                std::vector<int> member_of((size_t)sc->n_nodes, -1);
+                for (size_t k = 0; k < spheres.size(); ++k) member_of[(size_t)spheres[k]] = (int)k;
+                for (size_t k = 0; k < boxes.size(); ++k) member_of[(size_t)boxes[k]] = (int)(spheres.size() + k);
+                struct Emit {
+                    const rt_scene_desc* sc;
+                    std::vector<ReplayNode>& out;
+                    const std::vector<int>& member_of;
+                    void node(int id) {
+                        const rt_node& n = sc->nodes[id];
+                        ReplayNode r{};
+                        if (n.kind == RT_NODE_BVH) {
+                            for (int c = 0; c < 6; ++c) r.box[c] = n.p[c];
+                            r.member = -1;
+                            const size_t at = out.size();
+                            out.push_back(r);
+                            node(n.child0);
+                            node(n.child1);
+                            out[at].skip = (int32_t)out.size();
+                        } else {
+                            r.member = member_of[(size_t)id];
+                            r.skip = (int32_t)out.size() + 1;
+                            out.push_back(r);
+                        }
+                    }
+                } emit{sc, replay, member_of};
+                emit.node(idx);
+                rc = to_device(ctx, replay, &sd.replay);
+                if (rc != RT_OK) return rc;
+                sd.n_replay = (int32_t)replay.size();
+            }
             nodes[(size_t)idx].kind = DEV_NODE_LEAF_SET;  // p keeps the subtree's box
             nodes[(size_t)idx].a = (int32_t)sets.size();
             nodes[(size_t)idx].b = (int32_t)set_nodes.size();
@@ -1023,6 +1055,8 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     for (int i = 0; i < sc->n_textures; ++i) features |= scene_feature_bit_for_texture(sc->textures[i].kind);
     for (int i = 0; i < sc->n_materials; ++i) features |= scene_feature_bit_for_material(sc->materials[i].kind);
     for (const TopEntry& te : tops) features |= scene_feature_bit_for_top(te.end.kind);
+    for (const LeafSetDev& sd : sets)
+        if (sd.spheres.n > 0 && sd.boxes.n > 0) features |= scene_feature_bit_for_mixed_set();
     if (const char* v = std::getenv("RT_SCENE_VARIANT")) {
         if (std::strcmp(v, "all") == 0) features = ~0;
     }

@@ -101,9 +101,20 @@ struct BoxSetDev {
     BoxClustersDev clusters;
 };
 // The leaves of a DEV_NODE_LEAF_SET node: spheres, then boxes.
+// The subtree itself, for rays the float screens cannot hold (a NaN, an infinity, values whose products overflow: the
+// reference's own comparisons then come out false and order decides everything).  Its nodes in depth-first order; a
+// bvh_node whose box test fails is left by its skip link, so no stack is needed.
+struct ReplayNode {
+    double box[6];   // bvh_node: its box (B2/bvh.h:98)
+    int32_t skip;    // bvh_node: index of the node after its subtree
+    int32_t member;  // leaf: its index in the set (spheres first, then boxes); -1 for a bvh_node
+};
 struct LeafSetDev {
     SphereSetDev spheres;
     BoxSetDev boxes;
+    const ReplayNode* replay;
+    int32_t n_replay;
+    int32_t pad;
 };
 struct SphereListDev {
     SphereSetDev set;
@@ -269,6 +280,7 @@ void scene_probe_dump();  // debug build: prints and clears the traversal counte
 int scene_feature_bit_for_node(int node_kind);  // F_* bit a node / texture / material kind needs, 0 if none
 int scene_feature_bit_for_texture(int texture_kind);
 int scene_feature_bit_for_material(int material_kind);
+int scene_feature_bit_for_mixed_set();
 int scene_feature_bit_for_top(int end_kind);  // the stack-walk bit if a world object of this (device) kind needs it
 
 // Kernel launchers (rt_kernels_spheres.hip).  `blocks` = number of 256-thread workgroups.

@@ -331,6 +331,42 @@ static __device__ unsigned long long g_probe_mine[2][6];  // visits of a leaf se
 #else
 #define PROBE_MARK(k) do { } while (0)
 #endif
+// bvh_node::hit (B2/bvh.h:97-106) over the subtree of leaf set `set_index`, without the recursion: its nodes in
+// depth-first order, a node whose box test fails left by its skip link.  For the rays the flat form is not for.  Out of
+// line: it runs for a handful of rays in a launch, and inline its registers would be the render loop's.
+template <int F>
+__device__ __noinline__ Hit replay_subtree(const LeafSetDev* sets, const int32_t* set_nodes, int set_index, int first_slot, Ray loc,
+                                           int loc_xf, Hit h) {
+    const LeafSetDev set = sets[set_index];
+    const d3 loc_inv{1.0f / loc.d.x, 1.0f / loc.d.y, 1.0f / loc.d.z};
+    const double loc_a = len2(loc.d);
+    for (int at = 0; at < set.n_replay;) {
+        const ReplayNode rn = set.replay[at];
+        if (rn.member < 0) {
+            at = hit_aabb(rn.box, loc, loc_inv, T_MIN, h.t) ? at + 1 : rn.skip;
+            continue;
+        }
+        ++at;
+        if (rn.member < set.spheres.n) {
+            const SphereExact se = set.spheres.exact[rn.member];
+            double t;
+            if (hit_sphere(d3{se.cx, se.cy, se.cz}, se.radius, loc, loc_a, T_MIN, h.t, t)) {
+                h.t = t;
+                h.node = set_nodes[first_slot + rn.member];
+                h.xf = loc_xf;
+            }
+        } else if constexpr ((F & F_RECT) != 0) {
+            const BoxExact be = set.boxes.exact[rn.member - set.spheres.n];
+            const int side = hit_box6(be.corner, loc, T_MIN, h.t);
+            if (side >= 0) {
+                h.node = be.first_side + side;
+                h.xf = loc_xf;
+            }
+        }
+    }
+    return h;
+}
+
 template <int F>
 __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, bool exact_only, uint32_t* stack,
                                      int lane, const RngCtx& g) {
@@ -411,7 +447,22 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     // subtree keeps the smallest root in [t_min, closest so far] whatever order its leaves are tested
                     // in (B2/bvh.h:97-106), and so does the list
                     const d3 loc_inv{1.0f / loc.d.x, 1.0f / loc.d.y, 1.0f / loc.d.z};
-                    const bool mine = on && hit_aabb(n.p, loc, loc_inv, T_MIN, h.t);
+                    const bool reached = on && hit_aabb(n.p, loc, loc_inv, T_MIN, h.t);
+                    // A ray the float screens cannot hold -- a NaN, an infinity, products that overflow: the reference's
+                    // comparisons then come out false and the order of the tests decides everything -- walks the subtree
+                    // itself (replay_subtree); the flat form is for the others.  Only in the variants that carry the stack
+                    // loop as well: a call in the stack-free variants costs their render loop registers (final scene 42 ->
+                    // 46 ms), and their sets hold one kind of leaf (rt_scene_upload sends worlds with mixed sets here), for
+                    // which testing every member in order, as closest_hit_with does for such rays, gives the walk's answer.
+                    bool mine = reached;
+                    if constexpr ((F & F_STACK) != 0) {
+                        const double loc_a_ = len2(loc.d);
+                        const bool sane = fabs(loc.o.x) <= 1e15 && fabs(loc.o.y) <= 1e15 && fabs(loc.o.z) <= 1e15 && loc_a_ >= 1e-200 && loc_a_ <= 1e200;
+                        mine = reached && sane;
+                        if (ballot(reached && !sane) != 0ull) {
+                            if (reached && !sane) h = replay_subtree<F>(S.sets, S.set_nodes, n.a, n.b, loc, loc_xf, h);
+                        }
+                    }
                     if (ballot(mine) != 0ull) {
                         const LeafSetDev set = S.sets[n.a];
 #ifdef RT_SCENE_PROBE
@@ -1247,6 +1298,7 @@ int scene_feature_bit_for_texture(int kind) {
     return kind == RT_TEX_CHECKER ? F_CHECKER : kind == RT_TEX_NOISE ? F_NOISE : kind == RT_TEX_IMAGE ? F_IMAGE : 0;
 }
 int scene_feature_bit_for_material(int kind) { return kind == RT_MAT_ISOTROPIC ? F_MEDIUM : 0; }
+int scene_feature_bit_for_mixed_set() { return F_STACK; }  // a leaf set of spheres AND boxes: see trace()
 int scene_feature_bit_for_top(int end_kind) {  // end_kind: the device kind of a world object below its instance chain
     const bool in_the_wave_walk = (end_kind >= RT_NODE_SPHERE && end_kind <= RT_NODE_YZ_RECT) || end_kind == DEV_NODE_BOX6 ||
                                   end_kind == RT_NODE_MEDIUM || end_kind == DEV_NODE_LEAF_SET;

@@ -203,6 +203,27 @@ def test_random_world_matches_oracle(seed, monkeypatch):
         assert np.array_equal(ids, want_ids), (seed, set_min)
 
 
+def test_rays_that_overflow_walk_a_mixed_subtree_as_the_reference_does(monkeypatch):
+    """A lens radius of 1e300 gives every ray an origin and a direction of that size: |d|^2 overflows, a sphere's
+    discriminant is inf - inf = NaN and the sphere "hit" at t = NaN, while a box side is still met at a finite t -- which
+    leaf ends up as the hit then hangs on the order of the tests and on the boxes of the bvh_nodes in between.  A leaf set
+    that holds spheres AND boxes cannot tell from its two flat lists, so such rays walk the subtree itself (world 40516 of
+    tools/fuzz_sweep.py, found by it: every pixel differed)."""
+    scene = random_world(40516)
+    mk = lambda f: f((8, 3.5, 8), (0, 0.7, 0), (0, 1, 0), 32.0, 4.0 / 3.0, 1.0e300, 10.0, 0.0, 1.0)
+    cam, ocam = mk(lib.camera), mk(ob.camera)
+    p = abi.render_params(48, 36, 3, 50, seed=40516)
+    _, fixed, ost = ob.render(scene, ocam, p, rng=ob.RNG_PHILOX, assoc=ob.ASSOC_FORWARD, has_time=True, threads=16)
+    want = fixed.astype(np.float64) / FRAC
+    for set_min in (2, 1000):
+        monkeypatch.setenv("RT_SUBTREE_SET_MIN", str(set_min))
+        with lib.Context(0) as c:
+            c.upload(scene)
+            got, st = c.render(cam, p)
+        assert st["rays"] == ost["rays"], set_min
+        assert_sums_match(got, want, True, set_min)
+
+
 def random_sphere_world(seed):
     """Spheres and moving spheres only, in random nestings of lists and BVH nodes: runs on the sphere-list kernels."""
     rng = np.random.default_rng(seed)
