@@ -456,6 +456,9 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
             md.ay = sc->textures[m.texture].p[1];
             md.az = sc->textures[m.texture].p[2];
         }
+        // A dielectric has no albedo (its attenuation is white, B1/material.h:59); the slot carries 1.0 / ir, the
+        // refraction ratio of a front-face hit (B1/material.h:60), so that no lane divides for it
+        if (m.kind == RT_MAT_DIELECTRIC) md.ax = 1.0 / m.param;
         mats[i] = md;
     }
     return mats;

@@ -87,6 +87,48 @@ __device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {     
     return r_out_perp + r_out_parallel;
 }
 
+// ---------------------------------------------------------------- several quotients over one denominator
+// An IEEE double division is eleven vector instructions on gfx950: the denominator's reciprocal (v_rcp_f64 and two
+// Newton steps, five instructions), the quotient's estimate, its exact remainder and one correction (three), and three
+// more that rescale operands with extreme exponents and patch the special cases (v_div_scale twice, v_div_fixup).
+// Where several numerators meet the same denominator -- every root of a ray's sphere tests is (...) / |d|^2, both
+// jitter coordinates of a sample are divided by W-1 and H-1 -- the reciprocal is worked out once (SharedDivisor) and a
+// quotient costs the three instructions in the middle.  Same instructions on the same operands as the compiler's own
+// sequence whenever that sequence rescales nothing and patches nothing, i.e. the result is the correctly rounded
+// quotient bit for bit: denominator within [2^-60, 2^60], numerator zero or within [2^-200, 2^200] in magnitude (the
+// hardware rescales for exponents beyond +-700 or so only).  Any other operand takes the division itself.
+#ifndef RT_SHARED_DIVISOR
+#define RT_SHARED_DIVISOR 1
+#endif
+struct SharedDivisor {
+    double a;   // the denominator
+    double r;   // its reciprocal after two Newton steps, as the division sequence computes it
+    bool tame;  // a within [2^-60, 2^60]
+};
+__device__ __forceinline__ SharedDivisor shared_divisor(double a) {
+    SharedDivisor s;
+    s.a = a;
+    s.tame = a >= 0x1p-60 && a <= 0x1p60;
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    s.r = r;
+    return s;
+}
+// n / s.a for a numerator known to be +0 or within [2^-200, 2^200] and a tame denominator
+__device__ __forceinline__ double quotient_of_tame(double n, double a, double r) {
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-a, q, n), r, q);
+}
+// n / s.a
+__device__ __forceinline__ double quotient(double n, const SharedDivisor& s) {
+#if RT_SHARED_DIVISOR
+    const double m = fabs(n);
+    if (s.tame && m >= 0x1p-200 && m <= 0x1p200) return quotient_of_tame(n, s.a, s.r);
+#endif
+    return n / s.a;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 

@@ -52,6 +52,9 @@ namespace rtd {
 #ifndef RT_MIN_WAVES_TIMED
 #define RT_MIN_WAVES_TIMED 4
 #endif
+#ifndef RT_MERGED_UNIT_VECTOR
+#define RT_MERGED_UNIT_VECTOR 1
+#endif
 // texture::value of a lambertian's albedo for the textures a sphere world may use: solid_color and checker_texture
 // (B2/texture.h:23-25, 46-52), checkers nested at most three deep.
 __device__ __forceinline__ d3 sphere_world_texture(const SphereListDev& S, int ti, d3 p) {
@@ -83,6 +86,14 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const CameraDev& cam = s_cam[threadIdx.x >> 6];
+    // reciprocals of the jitter's two divisors (shared_divisor), one copy per wave like the camera
+    __shared__ double s_frame_rcp[4][2];
+    {
+        double* rcp = s_frame_rcp[threadIdx.x >> 6];
+        if (lane < 2) rcp[lane] = shared_divisor(lane == 0 ? A.width_m1 : A.height_m1).r;
+        lds_wave_sync();
+    }
+    const double* frame_rcp = s_frame_rcp[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
     const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, A.pixel_pass != 0);
@@ -130,7 +141,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                 const int i = (int)(w.pixel - row * (uint32_t)A.width);
                 const int j = A.height - 1 - (int)row;  // row 0 = top = j = H-1
                 camera_ray_for_lanes<TIMED, RT_COOP_CAMERA != 0>(start, cam, A.width_m1, A.height_m1, i, j, w.pixel, (uint32_t)w.s_cur, A.key0,
-                                                                 A.key1, lane, nullptr, o, d, tm);
+                                                                 A.key1, lane, nullptr, o, d, tm, frame_rcp);
             } else if (start) {  // (the book-2 variant is at its register limit: every lane computes its own blocks, in the branch)
                 const uint32_t row = div_by_width(w.pixel, A.wdiv.mul, A.wdiv.shift);
                 const int i = (int)(w.pixel - row * (uint32_t)A.width);
@@ -197,8 +208,13 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
             }
             // unit_vector(r.direction()) is wanted by the sky, by metal and by dielectric: one copy of the square
             // root and division for all of them instead of one per divergent branch
+            // -- and the lambertian's unit_vector(random_in_unit_sphere()) is the same function of another vector, wanted
+            // by exactly the lanes that do not want the direction's: one evaluation on each lane's own argument.
+            // (Where the sampler's vector is known by now: the variant that draws it inside the material's branch keeps two.)
+            constexpr bool MERGED = WAVE_BLOCKS && (RT_MERGED_UNIT_VECTOR != 0);
             d3 unit_direction{0, 0, 0};
-            if (!hit || m.kind != RT_MAT_LAMBERTIAN) unit_direction = unit_vector(d);
+            if constexpr (MERGED) unit_direction = unit_vector((hit && m.kind == RT_MAT_LAMBERTIAN) ? rs : d);
+            else if (!hit || m.kind != RT_MAT_LAMBERTIAN) unit_direction = unit_vector(d);
             if (!hit) {
                 if (S.sky_mode == RT_SKY_GRADIENT) {  // B1/RayTracing.cpp:28-30
                     const double t = 0.5 * (unit_direction.y + 1.0);
@@ -224,7 +240,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                                                A.key0, A.key1);
                 }
                 if (m.kind == RT_MAT_LAMBERTIAN) {  // B1/material.h:19-30
-                    nd = normal + unit_vector(rs);
+                    nd = normal + (MERGED ? unit_direction : unit_vector(rs));  // (MERGED: a lambertian lane's holds unit_vector(rs))
                     const double s = 1e-8;
                     if ((fabs(nd.x) < s) && (fabs(nd.y) < s) && (fabs(nd.z) < s)) nd = normal;
                 } else if (m.kind == RT_MAT_METAL) {  // B1/material.h:40-47
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     if (!(dot(nd, normal) > 0)) done = true;  // absorbed: black
                 } else {  // dielectric, B1/material.h:58-77
                     attenuation = d3{1.0, 1.0, 1.0};
-                    const double refraction_ratio = front_face ? (1.0 / m.param) : m.param;
+                    const double refraction_ratio = front_face ? m.ax : m.param;  // m.ax = 1.0 / ir (device_materials)
                     const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
                     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;

@@ -130,7 +130,7 @@ __device__ __forceinline__ void philox_blocks_for_lanes(bool want, uint32_t c0, 
 template <bool TIMED, bool COOP = (RT_COOP_CAMERA != 0)>
 __device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev& C, double wm1, double hm1, int i, int j, uint32_t pixel,
                                                      uint32_t sample, uint32_t k0, uint32_t k1, int lane, uint8_t* owners, d3& o,
-                                                     d3& d, double& tm) {
+                                                     d3& d, double& tm, const double* frame_rcp = nullptr) {
     if constexpr (!COOP) {
         if (start) {
             camera_ray(C, wm1, hm1, i, j, pixel, sample, k0, k1, o, d);
@@ -143,8 +143,16 @@ __device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev
     }
     u32x4 b[2];
     philox_blocks_for_lanes<2>(start, pixel, sample, 0u, 0u, TIMED ? TRY_TIME : 0u, k0, k1, lane, owners, b);
-    const double s = (i + u01(b[0].x)) / wm1;  // B1/RayTracing.cpp:120-121
-    const double t = (j + u01(b[0].y)) / hm1;
+    // B1/RayTracing.cpp:120-121.  frame_rcp = the reciprocals of shared_divisor(wm1) and shared_divisor(hm1), worked out
+    // once per wave: the numerators are 0 or within [2^-31, 2^28], the denominators within [1, 2^28].
+    double s, t;
+    if (frame_rcp != nullptr && RT_SHARED_DIVISOR != 0) {
+        s = quotient_of_tame(i + u01(b[0].x), wm1, frame_rcp[0]);
+        t = quotient_of_tame(j + u01(b[0].y), hm1, frame_rcp[1]);
+    } else {
+        s = (i + u01(b[0].x)) / wm1;
+        t = (j + u01(b[0].y)) / hm1;
+    }
     double px = u_range(b[0].z, -1, 1), py = u_range(b[0].w, -1, 1);
     bool need = start && px * px + py * py + 0.0 * 0.0 >= 1;  // random_in_unit_disk
     auto attempt = [&](uint32_t x, uint32_t y) {

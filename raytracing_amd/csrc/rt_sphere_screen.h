@@ -272,7 +272,9 @@ __device__ __forceinline__ d3 center_at(const SphereSetDev& S, int j, const Sphe
 }
 
 template <bool TIMED>
-__device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3 d, double a, double tm, double t_min, SetHit& h) {
+__device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3 d, const SharedDivisor& over_a, double tm, double t_min,
+                                          SetHit& h) {
+    const double a = over_a.a;  // |d|^2, the denominator of both roots (and of every other member's roots)
     const SphereExact e = S.exact[j];
     const d3 oc = o - center_at<TIMED>(S, j, e, tm);
     const double half_b = dot(oc, d);
@@ -280,9 +282,9 @@ __device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3
     const double discriminant = half_b * half_b - a * c;
     if (discriminant < 0) return;
     const double sqrtd = sqrt(discriminant);
-    double root = (-half_b - sqrtd) / a;
+    double root = quotient(-half_b - sqrtd, over_a);
     if (root < t_min || root > h.t) {
-        root = (-half_b + sqrtd) / a;
+        root = quotient(-half_b + sqrtd, over_a);
         if (root < t_min || root > h.t) return;
     }
     h.t = root;
@@ -502,7 +504,7 @@ template <bool TIMED>
 __device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d, double tm, double t_max, bool on, bool exact_only,
                                               uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
                                               ProbeClock& pc) {
-    const double a = len2(d);
+    const SharedDivisor a = shared_divisor(len2(d));
     const double t_min = 0.001;  // B1/RayTracing.cpp:17
 #if RT_SPREAD_LIST_TESTS
     return closest_hit_with(
@@ -510,7 +512,7 @@ __device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d,
         [&](int j, SetHit& h) { exact_one<TIMED>(S, j, o, d, a, tm, t_min, h); },
         [&](int j, d3 ro, d3 rd, double rt, double rtm, double& t) -> int {
             SetHit one{rt, -1};
-            exact_one<TIMED>(S, j, ro, rd, len2(rd), rtm, t_min, one);
+            exact_one<TIMED>(S, j, ro, rd, shared_divisor(len2(rd)), rtm, t_min, one);
             t = one.t;
             return one.id >= 0 ? 0 : -1;
         },
