@@ -769,8 +769,12 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
                               const std::vector<int>* tops) {
     const int n = (int)prims.size();
     const bool timed = tops != nullptr;
-    std::vector<int32_t> material_of((size_t)std::max(1, n));
-    for (int i = 0; i < n; ++i) material_of[i] = sc->nodes[prims[(size_t)i]].material;
+    std::vector<SphereShade> shade_of((size_t)std::max(1, n));
+    for (int i = 0; i < n; ++i) {
+        const rt_node& nd = sc->nodes[prims[(size_t)i]];
+        const double radius = nd.kind == RT_NODE_MOVING_SPHERE ? nd.p[8] : nd.p[3];
+        shade_of[(size_t)i] = SphereShade{1.0 / radius, nd.material, 0};
+    }
     std::vector<MaterialDev> mats = device_materials(sc);
     // the sphere kernels read a solid albedo from the material itself; tex stays only where a checker must be evaluated
     for (int i = 0; i < sc->n_materials; ++i) {
@@ -784,7 +788,7 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
     S = SphereListDev{};
     int rc;
     if ((rc = build_sphere_set(ctx, sc, prims, timed, true, S.set, ctx->sweep_lo, ctx->sweep_hi)) != RT_OK) return rc;
-    if ((rc = to_device(ctx, material_of, &S.material_of)) != RT_OK) return rc;
+    if ((rc = to_device(ctx, shade_of, &S.shade_of)) != RT_OK) return rc;
     if ((rc = to_device(ctx, mats, &S.materials)) != RT_OK) return rc;
     if (timed) {
         std::vector<int32_t> top_of(tops->begin(), tops->end());

@@ -80,12 +80,8 @@ __device__ __forceinline__ double len2(d3 a) { return a.x * a.x + a.y * a.y + a.
 __device__ __forceinline__ d3 div_by(d3 a, double t) { return (1 / t) * a; }
 __device__ __forceinline__ d3 unit_vector(d3 a) { return div_by(a, sqrt(len2(a))); }
 __device__ __forceinline__ d3 reflect(d3 v, d3 n) { return v - (2 * dot(v, n)) * n; }  // B1/vec3.h:134-136
-__device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {            // B1/vec3.h:138-143
-    const double cos_theta = fmin(dot(-uv, n), 1.0);
-    const d3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
-    const d3 r_out_parallel = (-sqrt(fabs(1.0 - len2(r_out_perp)))) * n;
-    return r_out_perp + r_out_parallel;
-}
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // ---------------------------------------------------------------- several quotients over one denominator
 // An IEEE double division is eleven vector instructions on gfx950: the denominator's reciprocal (v_rcp_f64 and two
@@ -97,6 +93,12 @@ __device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {     
 // sequence whenever that sequence rescales nothing and patches nothing, i.e. the result is the correctly rounded
 // quotient bit for bit: denominator within [2^-60, 2^60], numerator zero or within [2^-200, 2^200] in magnitude (the
 // hardware rescales for exponents beyond +-700 or so only).  Any other operand takes the division itself.
+// RT_ISSUE_BOUND: set by the translation unit of the sphere-list kernels, which are bound by vector issue -- every
+// instruction saved is time saved.  The scene-graph kernels wait on loads and are short of registers: the same
+// rewrites change nothing there or cost (the final scene's variant loses 8 % to them), so their unit leaves it unset.
+#ifndef RT_ISSUE_BOUND
+#define RT_ISSUE_BOUND 0
+#endif
 #ifndef RT_SHARED_DIVISOR
 #define RT_SHARED_DIVISOR 1
 #endif
@@ -129,8 +131,51 @@ __device__ __forceinline__ double quotient(double n, const SharedDivisor& s) {
     return n / s.a;
 }
 
+// The same for square roots: the compiler's sqrt(double) is a reciprocal square root refined to the correctly rounded
+// root (v_rsq_f64 and ten multiply-adds) wrapped in eight more instructions that rescale arguments below 2^-767 and pass
+// zeros and infinities through.  For an argument within [2^-700, 2^700] the ten alone give the same bits.
+__device__ __forceinline__ double sqrt_of_tame(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return g;
+}
+__device__ __forceinline__ double sqrt_shared(double x) {
+#if RT_SHARED_DIVISOR
+    if (x >= 0x1p-700 && x <= 0x1p700) return sqrt_of_tame(x);
+#endif
+    return sqrt(x);
+}
+// unit_vector(v) = (1 / sqrt(|v|^2)) * v (B1/vec3.h:96-98, 153-155): one range test covers root and reciprocal
+// (all lanes of the wave that call it take the same way: one scalar branch)
+__device__ __forceinline__ d3 unit_vector_shared(d3 v) {
+#if RT_SHARED_DIVISOR
+    const double l2 = len2(v);
+    if (ballot(!(l2 >= 0x1p-120 && l2 <= 0x1p120)) == 0ull) {
+        const double l = sqrt_of_tame(l2);
+        return quotient_of_tame(1.0, l, shared_divisor(l).r) * v;
+    }
+#endif
+    return unit_vector(v);
+}
+
+__device__ __forceinline__ d3 refract(d3 uv, d3 n, double etai_over_etat) {            // B1/vec3.h:138-143
+    const double cos_theta = fmin(dot(-uv, n), 1.0);
+    const d3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+#if RT_ISSUE_BOUND
+    const d3 r_out_parallel = (-sqrt_shared(fabs(1.0 - len2(r_out_perp)))) * n;
+#else
+    const d3 r_out_parallel = (-sqrt(fabs(1.0 - len2(r_out_perp)))) * n;
+#endif
+    return r_out_perp + r_out_parallel;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // What the lanes of this wave wrote to LDS before is visible to all of them after.
 __device__ __forceinline__ void lds_wave_sync() {

@@ -116,9 +116,15 @@ struct LeafSetDev {
     int32_t n_replay;
     int32_t pad;
 };
+// What shading a hit on sphere j needs beyond its SphereExact record, in one 16-byte load.
+struct SphereShade {
+    double inv_radius;  // 1.0 / radius: the factor of (p - center) / radius, B1/sphere.h:46, B1/vec3.h:96-98
+    int32_t material;
+    int32_t pad;
+};
 struct SphereListDev {
     SphereSetDev set;
-    const int32_t* material_of;
+    const SphereShade* shade_of;
     const MaterialDev* materials;
     int32_t sky_mode;
     double background[3];

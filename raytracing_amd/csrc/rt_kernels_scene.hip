@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
                     if (!importance && !(dot(nd, s.normal) > 0)) done = true;
                 } else if (m.kind == RT_MAT_DIELECTRIC) {  // B2/material.h:64-83
                     attenuation = d3{1.0, 1.0, 1.0};
-                    const double refraction_ratio = s.front_face ? m.ax : m.param;  // m.ax = 1.0 / ir (device_materials)
+                    const double refraction_ratio = s.front_face ? (1.0 / m.param) : m.param;
                     const d3 unit_direction = unit_vector(r.d);
                     const double cos_theta = fmin(dot(-unit_direction, s.normal), 1.0);
                     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);

@@ -30,6 +30,7 @@
 // The float screen can only add candidates, never drop a true hit (bound in screen_prepare),
 // so the rendered numbers are those of an all-double renderer.
 #define RT_PHILOX_OPAQUE_KEY 1  // see philox4x32_10
+#define RT_ISSUE_BOUND 1        // see rt_device_common.h
 #include "rt_device_common.h"
 #include "rt_internal.h"
 #include "rt_render_common.h"
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
         if constexpr (WAVE_BLOCKS) {
             int mat_kind = RT_MAT_DIELECTRIC;
             if (hit) {
-                mat = S.material_of[h.id];
+                mat = S.shade_of[h.id].material;
                 mat_kind = S.materials[mat].kind;
             }
             const bool wants_sphere = hit && (mat_kind == RT_MAT_LAMBERTIAN || mat_kind == RT_MAT_METAL);
@@ -201,9 +202,12 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
             d3 L_end{0, 0, 0};
             SphereExact e{0, 0, 0, 1};
             MaterialDev m{RT_MAT_LAMBERTIAN, -1, 0, 0, 0, 0};
+            double inv_radius = 1.0;
             if (hit) {
                 e = S.set.exact[h.id];
-                if constexpr (!WAVE_BLOCKS) mat = S.material_of[h.id];
+                const SphereShade sh = S.shade_of[h.id];
+                inv_radius = sh.inv_radius;
+                if constexpr (!WAVE_BLOCKS) mat = sh.material;
                 m = S.materials[mat];
             }
             // unit_vector(r.direction()) is wanted by the sky, by metal and by dielectric: one copy of the square
@@ -213,8 +217,9 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
             // (Where the sampler's vector is known by now: the variant that draws it inside the material's branch keeps two.)
             constexpr bool MERGED = WAVE_BLOCKS && (RT_MERGED_UNIT_VECTOR != 0);
             d3 unit_direction{0, 0, 0};
-            if constexpr (MERGED) unit_direction = unit_vector((hit && m.kind == RT_MAT_LAMBERTIAN) ? rs : d);
-            else if (!hit || m.kind != RT_MAT_LAMBERTIAN) unit_direction = unit_vector(d);
+            constexpr bool SHORT = !TIMED || RT_TIMED_SHARED_DIVISOR != 0;  // roots and quotients without rescaling (rt_device_common.h)
+            if constexpr (MERGED) unit_direction = unit_vector_shared((hit && m.kind == RT_MAT_LAMBERTIAN) ? rs : d);
+            else if (!hit || m.kind != RT_MAT_LAMBERTIAN) unit_direction = SHORT ? unit_vector_shared(d) : unit_vector(d);
             if (!hit) {
                 if (S.sky_mode == RT_SKY_GRADIENT) {  // B1/RayTracing.cpp:28-30
                     const double t = 0.5 * (unit_direction.y + 1.0);
@@ -226,7 +231,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
             } else {
                 // rest of sphere::hit, B1/sphere.h:43-47
                 const d3 p = o + h.t * d;
-                const d3 outward_normal = div_by(p - center_at<TIMED>(S.set, h.id, e, tm), e.radius);
+                const d3 outward_normal = inv_radius * (p - center_at<TIMED>(S.set, h.id, e, tm));  // (p - center) / radius
                 const bool front_face = dot(d, outward_normal) < 0;
                 const d3 normal = front_face ? outward_normal : -outward_normal;
                 d3 attenuation{m.ax, m.ay, m.az};
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                                                A.key0, A.key1);
                 }
                 if (m.kind == RT_MAT_LAMBERTIAN) {  // B1/material.h:19-30
-                    nd = normal + (MERGED ? unit_direction : unit_vector(rs));  // (MERGED: a lambertian lane's holds unit_vector(rs))
+                    nd = normal + (MERGED ? unit_direction : (SHORT ? unit_vector_shared(rs) : unit_vector(rs)));  // (MERGED: a lambertian lane's holds unit_vector(rs))
                     const double s = 1e-8;
                     if ((fabs(nd.x) < s) && (fabs(nd.y) < s) && (fabs(nd.z) < s)) nd = normal;
                 } else if (m.kind == RT_MAT_METAL) {  // B1/material.h:40-47
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     attenuation = d3{1.0, 1.0, 1.0};
                     const double refraction_ratio = front_face ? m.ax : m.param;  // m.ax = 1.0 / ir (device_materials)
                     const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
-                    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                    const double sin_theta = SHORT ? sqrt_shared(1.0 - cos_theta * cos_theta) : sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
                     if (!do_reflect) do_reflect = reflectance(cos_theta, refraction_ratio) > u01(block0.x);
                     nd = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);

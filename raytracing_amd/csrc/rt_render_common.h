@@ -37,12 +37,61 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, double wm1, doubl
     d = llc + s * hor + t * ver - origin - offset;
 }
 
+// Whether the point p = (u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)) of three Philox words passes the test
+// of the unit-sphere rejection loop, !(p.length_squared() >= 1) (B1/vec3.h:117), without the doubles.  A coordinate is
+// exactly m 2^-30 with m = (word >> 1) - 2^30, so |p|^2 = S 2^-60 with the integer S = mx^2 + my^2 + mz^2 < 2^62.  The
+// reference adds the three rounded squares in double: near 1 its sum is within 2^-51 of S 2^-60 (three roundings of
+// values below 1, two of sums below 2), so S decides unless it lies within 2^10 of 2^60 -- then the doubles are evaluated.
+// Eight vector instructions instead of twenty per attempt; the accepted point is converted once, after the loop.
+// (Sphere-list kernels, bound by vector issue; the scene-graph kernels wait on loads and are short of registers: the
+// final scene's variant loses 8 % to it.)
+#ifndef RT_INTEGER_SPHERE_TEST
+#define RT_INTEGER_SPHERE_TEST RT_ISSUE_BOUND
+#endif
+__device__ __forceinline__ bool inside_unit_sphere(uint32_t x, uint32_t y, uint32_t z) {
+#if RT_INTEGER_SPHERE_TEST
+    const int32_t mx = (int32_t)(x >> 1) - (1 << 30), my = (int32_t)(y >> 1) - (1 << 30), mz = (int32_t)(z >> 1) - (1 << 30);
+    const uint64_t S = (uint64_t)((int64_t)mx * mx) + (uint64_t)((int64_t)my * my) + (uint64_t)((int64_t)mz * mz);
+    if (S < (1ull << 60) - 1024ull) return true;
+    if (S > (1ull << 60) + 1024ull) return false;
+#endif
+    const d3 p{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
+    return !(len2(p) >= 1);
+}
+
+// One lane's state across the attempts of the unit-sphere rejection loop: with the integer test the words of the attempt
+// that passed, converted once at the end; otherwise the point itself, as the reference computes it attempt by attempt.
+struct SpherePoint {
+    bool wanted = false;
+#if RT_INTEGER_SPHERE_TEST
+    uint32_t kx = 0, ky = 0, kz = 0;
+    __device__ __forceinline__ bool attempt(uint32_t x, uint32_t y, uint32_t z) {
+        if (!inside_unit_sphere(x, y, z)) return false;
+        kx = x;
+        ky = y;
+        kz = z;
+        return true;
+    }
+    __device__ __forceinline__ d3 value() const {
+        return wanted ? d3{u_range(kx, -1, 1), u_range(ky, -1, 1), u_range(kz, -1, 1)} : d3{0, 0, 0};
+    }
+#else
+    d3 p{0, 0, 0};
+    __device__ __forceinline__ bool attempt(uint32_t x, uint32_t y, uint32_t z) {
+        p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
+        return !(len2(p) >= 1);
+    }
+    __device__ __forceinline__ d3 value() const { return p; }
+#endif
+};
+
 // random_in_unit_sphere, B1/vec3.h:114-120, for the lanes with need == true.  block0 = Philox block 0 of the site,
 // computed by the caller (the dielectric's reflectance draw of the same site reads the same block: one evaluation
 // serves the lanes of either kind).
 __device__ __forceinline__ d3 random_in_unit_sphere(bool need, u32x4 block0, uint32_t pixel, uint32_t sample, uint32_t site,
                                                     uint32_t k0, uint32_t k1) {
-    d3 p{0, 0, 0};
+    SpherePoint p;
+    p.wanted = need;
     uint32_t sx = 0, sy = 0, sz = 0;  // words 3 of the last three blocks: the fourth attempt of each group
     for (uint32_t k = 0; need; ++k) {
         uint32_t x, y, z;
@@ -59,10 +108,9 @@ __device__ __forceinline__ d3 random_in_unit_sphere(bool need, u32x4 block0, uin
             sy = (k & 3u) == 1u ? w.w : sy;
             sz = (k & 3u) == 2u ? w.w : sz;
         }
-        p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
-        if (!(len2(p) >= 1)) need = false;
+        if (p.attempt(x, y, z)) need = false;
     }
-    return p;
+    return p.value();
 }
 
 // ---------------------------------------------------------------- Philox blocks computed by the wave for its lanes
@@ -198,15 +246,14 @@ template <bool COOP = (RT_COOP_SHADE != 0)>
 __device__ __forceinline__ d3 random_in_unit_sphere_for_lanes(bool need, u32x4 block0, uint32_t pixel, uint32_t sample,
                                                               uint32_t site, uint32_t k0, uint32_t k1, int lane, uint8_t* owners) {
     if constexpr (!COOP) return random_in_unit_sphere(need, block0, pixel, sample, site, k0, k1);
-    d3 p{0, 0, 0};
+    SpherePoint p;
+    p.wanted = need;
     auto attempt = [&](uint32_t x, uint32_t y, uint32_t z) {
-        if (need) {
-            p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
-            if (!(len2(p) >= 1)) need = false;
-        }
+        if (need && p.attempt(x, y, z)) need = false;
     };
+    auto point = [&]() { return p.value(); };
     attempt(block0.x, block0.y, block0.z);
-    if (ballot(need) == 0ull) return p;
+    if (ballot(need) == 0ull) return point();
     {
         u32x4 b[2];
         philox_blocks_for_lanes<2>(need, pixel, sample, site, 1u, 0u, k0, k1, lane, owners, b);
@@ -222,7 +269,7 @@ __device__ __forceinline__ d3 random_in_unit_sphere_for_lanes(bool need, u32x4 b
         if (ballot(need) != 0ull) attempt(b[2].x, b[2].y, b[2].z);
         if (ballot(need) != 0ull) attempt(b[0].w, b[1].w, b[2].w);
     }
-    return p;
+    return point();
 }
 
 __device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  // B1/material.h:83-88

@@ -271,20 +271,54 @@ __device__ __forceinline__ d3 center_at(const SphereSetDev& S, int j, const Sphe
     return center;
 }
 
+// A ray whose roots may take the short division and square root (rt_device_common.h) for every sphere the float screen
+// holds (coordinates and radii of at most 1e15 < 2^50): |d|^2 within [2^-60, 2^60] and origin coordinates of at most 2^60
+// bound both numerators, -half_b -+ sqrt(discriminant), by 2^94 and the discriminant by 2^190, so nothing is rescaled
+// from above.  From below the division needs no bound here: a numerator under 2^-200 gives a root under 2^-140 either
+// way, which t_min (1e-3 in every caller) rejects, as it does the root the division itself would give; the square root
+// keeps its own test of the discriminant's lower end.
+struct RootsOf {
+    SharedDivisor over_a;  // |d|^2
+    bool fast;             // the whole wave's rays are of that kind (wave-uniform: one scalar branch per use)
+};
+__device__ __forceinline__ RootsOf roots_of(d3 o, d3 d, bool on, bool allow) {
+    RootsOf r;
+    r.over_a = shared_divisor(len2(d));
+    const bool tame = r.over_a.tame && fabs(o.x) <= 0x1p60 && fabs(o.y) <= 0x1p60 && fabs(o.z) <= 0x1p60;
+    r.fast = allow && RT_SHARED_DIVISOR != 0 && ballot(on && !tame) == 0ull;
+    return r;
+}
+
 template <bool TIMED>
-__device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3 d, const SharedDivisor& over_a, double tm, double t_min,
-                                          SetHit& h) {
-    const double a = over_a.a;  // |d|^2, the denominator of both roots (and of every other member's roots)
+__device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3 d, const RootsOf& ray, double tm, double t_min, SetHit& h) {
+    const double a = ray.over_a.a;  // |d|^2, the denominator of both roots (and of every other member's roots)
     const SphereExact e = S.exact[j];
     const d3 oc = o - center_at<TIMED>(S, j, e, tm);
     const double half_b = dot(oc, d);
     const double c = len2(oc) - e.radius * e.radius;
     const double discriminant = half_b * half_b - a * c;
+    if (ray.fast) {
+        double sqrtd;
+        if (discriminant >= 0x1p-700) {
+            sqrtd = sqrt_of_tame(discriminant);
+        } else {
+            if (discriminant < 0) return;
+            sqrtd = sqrt(discriminant);  // zero, or next to nothing (or a NaN)
+        }
+        double root = quotient_of_tame(-half_b - sqrtd, a, ray.over_a.r);
+        if (root < t_min || root > h.t) {
+            root = quotient_of_tame(-half_b + sqrtd, a, ray.over_a.r);
+            if (root < t_min || root > h.t) return;
+        }
+        h.t = root;
+        h.id = j;
+        return;
+    }
     if (discriminant < 0) return;
     const double sqrtd = sqrt(discriminant);
-    double root = quotient(-half_b - sqrtd, over_a);
+    double root = (-half_b - sqrtd) / a;
     if (root < t_min || root > h.t) {
-        root = quotient(-half_b + sqrtd, over_a);
+        root = (-half_b + sqrtd) / a;
         if (root < t_min || root > h.t) return;
     }
     h.t = root;
@@ -497,6 +531,9 @@ __device__ __forceinline__ SetHit closest_hit_with(const SphereSetDev& S, d3 o, 
 
 // The set's members are its spheres themselves (sphere-list kernels).  RT_SPREAD_LIST_TESTS: their double-precision tests
 // handed round the wave as well.
+#ifndef RT_TIMED_SHARED_DIVISOR
+#define RT_TIMED_SHARED_DIVISOR 1
+#endif
 #ifndef RT_SPREAD_LIST_TESTS
 #define RT_SPREAD_LIST_TESTS 0
 #endif
@@ -504,15 +541,16 @@ template <bool TIMED>
 __device__ __forceinline__ SetHit closest_hit(const SphereSetDev& S, d3 o, d3 d, double tm, double t_max, bool on, bool exact_only,
                                               uint16_t* list, uint32_t* rows, int lane, uint32_t& overflow_count,
                                               ProbeClock& pc) {
-    const SharedDivisor a = shared_divisor(len2(d));
     const double t_min = 0.001;  // B1/RayTracing.cpp:17
+    // (exact_only: the set may hold spheres beyond the float screen's range, which the bounds of roots_of do not cover)
+    const RootsOf a = roots_of(o, d, on, !exact_only && (!TIMED || RT_TIMED_SHARED_DIVISOR != 0));
 #if RT_SPREAD_LIST_TESTS
     return closest_hit_with(
         S, o, d, t_max, on, exact_only, list, rows, lane, overflow_count, pc,
         [&](int j, SetHit& h) { exact_one<TIMED>(S, j, o, d, a, tm, t_min, h); },
         [&](int j, d3 ro, d3 rd, double rt, double rtm, double& t) -> int {
             SetHit one{rt, -1};
-            exact_one<TIMED>(S, j, ro, rd, shared_divisor(len2(rd)), rtm, t_min, one);
+            exact_one<TIMED>(S, j, ro, rd, roots_of(ro, rd, true, false), rtm, t_min, one);
             t = one.t;
             return one.id >= 0 ? 0 : -1;
         },
