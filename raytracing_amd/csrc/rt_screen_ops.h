@@ -42,8 +42,30 @@ __device__ __forceinline__ f2 splat(double x) {
     return f2{f, f};
 }
 
+// The ray constants of the two screens feed float arithmetic whose margins are sized for inputs rounded to float
+// (relative 2^-24): a reciprocal or reciprocal square root good to 2^-45 serves as well as the correctly rounded one.
+// The hardware's estimate (v_rcp_f64, v_rsq_f64: about 2^-26) and one Newton step: 3 and 5 vector instructions where
+// the IEEE division takes 11 and 1 / sqrt(a) 30.  Used where vector issue is the bound (RT_ISSUE_BOUND); arguments
+// outside [1e-200, 1e200] give values no screen uses (such rays take the unscreened tests).
+__device__ __forceinline__ double reciprocal_for_screen(double x) {
+#if RT_ISSUE_BOUND
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#else
+    return 1.0 / x;
+#endif
+}
+__device__ __forceinline__ double rsqrt_for_screen(double a) {
+#if RT_ISSUE_BOUND
+    const double y = __builtin_amdgcn_rsq(a);
+    return __builtin_fma(y, __builtin_fma(-(a * y), 0.5 * y, 0.5), y);
+#else
+    return 1.0 / sqrt(a);
+#endif
+}
+
 __device__ __forceinline__ ScreenRay screen_prepare(d3 o, d3 d, double a /* |d|^2 */) {
-    const double inv_len = 1.0 / sqrt(a);
+    const double inv_len = rsqrt_for_screen(a);
     const d3 dh = inv_len * d;
     const double oo = len2(o);
     ScreenRay s;
@@ -117,7 +139,7 @@ __device__ __forceinline__ BoxScreenRay box_screen_prepare(d3 o, d3 d, double co
     for (int k = 0; k < 3; ++k) {
         const double ad = fabs(dk[k]), ao = fabs(ok[k]);
         if (!(ad >= 1e-30 && ad <= 1e30 && ao <= cover)) s.covered = false;
-        const double inv = 1.0 / dk[k];
+        const double inv = reciprocal_for_screen(dk[k]);
         s.inv[k] = splat(inv);
         s.ainv[k] = f2{fabsf(s.inv[k].x), fabsf(s.inv[k].x)};
         s.c[k] = splat(-ok[k] * inv);

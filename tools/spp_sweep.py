@@ -15,6 +15,7 @@ scene = abi.load_scene(os.path.join(ROOT, "tests", "golden", "scene_c2.rtsc"))
 cam = lib.camera(*CAM_C2)
 ctx = lib.Context(0)
 ctx.upload(scene)
+ctx.render(cam, abi.render_params(1200, 800, 250, 50, seed=1))  # warm-up: clocks, code objects, staging buffers
 rows = []
 for spp in (62, 63, 125, 250, 500):
     best = None
