@@ -563,6 +563,21 @@ __device__ __forceinline__ bool refill_work(const WorkQueues& Q, const ItemPlan&
 // a channel of RT_ACCUM_SAMPLE_LIMIT or more in magnitude, an infinity, a NaN (every comparison with one is false) --
 // is dropped and counted (the reference would carry it into its image).
 __device__ __forceinline__ void add_sample(d3 c, int64_t& fx, int64_t& fy, int64_t& fz, uint32_t& n_bad) {
+#if RT_ISSUE_BOUND
+    // A double has no conversion to a 64-bit integer in hardware (eight instructions per channel).  Below 2^51 the
+    // rounded integer can be read off the sum with 1.5 * 2^52 instead: the scaling by a power of two is exact, the
+    // one rounding of the multiply-add is to the nearest integer, ties to even -- what __double2ll_rn does --, and the
+    // sum's bit pattern is that of 1.5 * 2^52 plus the integer (two's complement).  Three instructions per channel.
+    constexpr double SMALL = (double)(1ull << (51 - RT_ACCUM_FRAC_BITS));
+    if (ballot(!(fabs(c.x) < SMALL && fabs(c.y) < SMALL && fabs(c.z) < SMALL)) == 0ull) {
+        constexpr double MAGIC = 0x1.8p52;
+        constexpr long long MAGIC_BITS = 0x4338000000000000ll;
+        fx += __double_as_longlong(__builtin_fma(c.x, ACCUM_SCALE, MAGIC)) - MAGIC_BITS;
+        fy += __double_as_longlong(__builtin_fma(c.y, ACCUM_SCALE, MAGIC)) - MAGIC_BITS;
+        fz += __double_as_longlong(__builtin_fma(c.z, ACCUM_SCALE, MAGIC)) - MAGIC_BITS;
+        return;
+    }
+#endif
     if (fabs(c.x) < RT_ACCUM_SAMPLE_LIMIT && fabs(c.y) < RT_ACCUM_SAMPLE_LIMIT && fabs(c.z) < RT_ACCUM_SAMPLE_LIMIT) {
         fx += __double2ll_rn(c.x * ACCUM_SCALE);
         fy += __double2ll_rn(c.y * ACCUM_SCALE);
