@@ -15,15 +15,15 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, double wm1, doubl
     u32x4 w = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
     const double s = (i + u01(w.x)) / wm1;  // B1/RayTracing.cpp:120-121
     const double t = (j + u01(w.y)) / hm1;
-    double px = u_range(w.z, -1, 1), py = u_range(w.w, -1, 1);
+    double px = u_signed(w.z), py = u_signed(w.w);
     for (uint32_t k = 1; px * px + py * py + 0.0 * 0.0 >= 1; ++k) {  // random_in_unit_disk
         if (k & 1u) {  // a new block every second attempt
             w = philox4x32_10(pixel, sample, 0u, (k + 1u) >> 1, k0, k1);
-            px = u_range(w.x, -1, 1);
-            py = u_range(w.y, -1, 1);
+            px = u_signed(w.x);
+            py = u_signed(w.y);
         } else {
-            px = u_range(w.z, -1, 1);
-            py = u_range(w.w, -1, 1);
+            px = u_signed(w.z);
+            py = u_signed(w.w);
         }
     }
     const double rdx = C.lens_radius * px, rdy = C.lens_radius * py;
@@ -37,7 +37,7 @@ __device__ __forceinline__ void camera_ray(const CameraDev& C, double wm1, doubl
     d = llc + s * hor + t * ver - origin - offset;
 }
 
-// Whether the point p = (u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)) of three Philox words passes the test
+// Whether the point p = (u_signed(x), u_signed(y), u_signed(z)) of three Philox words passes the test
 // of the unit-sphere rejection loop, !(p.length_squared() >= 1) (B1/vec3.h:117), without the doubles.  A coordinate is
 // exactly m 2^-30 with m = (word >> 1) - 2^30, so |p|^2 = S 2^-60 with the integer S = mx^2 + my^2 + mz^2 < 2^62.  The
 // reference adds the three rounded squares in double: near 1 its sum is within 2^-51 of S 2^-60 (three roundings of
@@ -55,7 +55,7 @@ __device__ __forceinline__ bool inside_unit_sphere(uint32_t x, uint32_t y, uint3
     if (S < (1ull << 60) - 1024ull) return true;
     if (S > (1ull << 60) + 1024ull) return false;
 #endif
-    const d3 p{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
+    const d3 p{u_signed(x), u_signed(y), u_signed(z)};
     return !(len2(p) >= 1);
 }
 
@@ -73,12 +73,12 @@ struct SpherePoint {
         return true;
     }
     __device__ __forceinline__ d3 value() const {
-        return wanted ? d3{u_range(kx, -1, 1), u_range(ky, -1, 1), u_range(kz, -1, 1)} : d3{0, 0, 0};
+        return wanted ? d3{u_signed(kx), u_signed(ky), u_signed(kz)} : d3{0, 0, 0};
     }
 #else
     d3 p{0, 0, 0};
     __device__ __forceinline__ bool attempt(uint32_t x, uint32_t y, uint32_t z) {
-        p = d3{u_range(x, -1, 1), u_range(y, -1, 1), u_range(z, -1, 1)};
+        p = d3{u_signed(x), u_signed(y), u_signed(z)};
         return !(len2(p) >= 1);
     }
     __device__ __forceinline__ d3 value() const { return p; }
@@ -201,12 +201,12 @@ __device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev
         s = (i + u01(b[0].x)) / wm1;
         t = (j + u01(b[0].y)) / hm1;
     }
-    double px = u_range(b[0].z, -1, 1), py = u_range(b[0].w, -1, 1);
+    double px = u_signed(b[0].z), py = u_signed(b[0].w);
     bool need = start && px * px + py * py + 0.0 * 0.0 >= 1;  // random_in_unit_disk
     auto attempt = [&](uint32_t x, uint32_t y) {
         if (need) {
-            px = u_range(x, -1, 1);
-            py = u_range(y, -1, 1);
+            px = u_signed(x);
+            py = u_signed(y);
             need = px * px + py * py + 0.0 * 0.0 >= 1;
         }
     };

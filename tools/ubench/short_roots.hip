@@ -3,6 +3,7 @@
 //   quotient_of_tame(n, a, shared_divisor(a).r)   vs  n / a          a in [2^-60, 2^60], |n| in [2^-200, 2^200], and n = 0
 //   sqrt_of_tame(x)                               vs  sqrt(x)        x in [2^-700, 2^700]
 //   inside_unit_sphere(x, y, z)                   vs  !(len2(p) >= 1), p = u_range(word, -1, 1)
+//   u_signed(word)                                vs  u_range(word, -1, 1)   for every 31-bit draw
 // Operands: random mantissas with exponents spread over the whole allowed range, plus the ends of the ranges, and for
 // the sphere test random words plus triples searched for whose |p|^2 lands within about 2^10 of 2^60 (where the
 // integer test hands over to the doubles).  Prints the number of results that differ bit for bit (expected: 0 everywhere), and checks
@@ -48,6 +49,17 @@ __global__ void k_sphere(int n, const uint32_t* w, uint8_t* fast, uint8_t* slow)
     slow[i] = !(len2(p) >= 1) ? 1 : 0;
 }
 
+__global__ void k_signed(uint32_t first, unsigned long long* differing) {  // all 2^31 draws, 2^8 per thread
+    const uint32_t base = first + (blockIdx.x * blockDim.x + threadIdx.x) * 256u;
+    unsigned long long d = 0;
+    for (uint32_t i = 0; i < 256u; ++i) {
+        const uint32_t word = (base + i) << 1;
+        const double a = u_signed(word), b = u_range(word, -1, 1), c = u_signed(word | 1u);
+        d += (__double_as_longlong(a) != __double_as_longlong(b)) + (__double_as_longlong(a) != __double_as_longlong(c));
+    }
+    if (d) atomicAdd(differing, d);
+}
+
 template <class T>
 static T* to_dev(const std::vector<T>& v) {
     T* p = nullptr;
@@ -74,6 +86,15 @@ int main() {
     auto spread = [&](int lo, int hi) { return std::ldexp(mantissa(), lo + (int)(g() % (uint64_t)(hi - lo))); };
     int bad = 0;
 
+    {   // u_signed against u_range(word, -1, 1), every 31-bit draw
+        unsigned long long* d;
+        (void)hipMalloc(&d, 8);
+        (void)hipMemset(d, 0, 8);
+        hipLaunchKernelGGL(k_signed, dim3((1u << 31) / 256u / 256u), dim3(256), 0, 0, 0u, d);
+        const auto v = from_dev(d, 1);
+        std::printf("draw in (-1,1) all 2^31 draws: u_signed differs from u_range(word, -1, 1) in %llu\n", v[0]);
+        bad += v[0] != 0;
+    }
     {   // division
         std::vector<double> num(n), den(n);
         for (int i = 0; i < n; ++i) {
