@@ -239,6 +239,56 @@ __device__ __forceinline__ void camera_ray_for_lanes(bool start, const CameraDev
     }
 }
 
+// The later attempts of the unit-sphere rejection loop, when at most four lanes of the wave are still in it (after four
+// attempts 5 % of the lanes that wanted a point are: two or three of a wave).  Each of them is served by sixteen lanes
+// that compute the blocks AND test the attempts, laid out in the order of the attempts: lanes 4i, 4i+1, 4i+2 of the
+// sixteen hold blocks 3(g+i), 3(g+i)+1, 3(g+i)+2 and test their words 0, 1, 2 (attempts 4(g+i) .. 4(g+i)+2), lane 4i+3
+// gathers the three words 3 of its neighbours (attempt 4(g+i)+3).  One ballot then holds, per owner, sixteen attempts in
+// order: its lowest set bit names the lane whose words the reference's loop would have accepted.  One Philox evaluation
+// and one test for sixteen attempts, where the owner's own loop tests four per evaluation one after the other (and the
+// chance of needing another round falls from 5 % to 10^-5).  Same blocks, same words, same order: same point.
+// Returns false, with nothing done, when more than four lanes need attempts.  All 64 lanes must call it.
+#ifndef RT_SPHERE_ATTEMPTS_BY_HELPERS
+#define RT_SPHERE_ATTEMPTS_BY_HELPERS 1
+#endif
+#if RT_INTEGER_SPHERE_TEST
+__device__ __forceinline__ bool sphere_attempts_by_helpers(bool& need, SpherePoint& p, uint32_t pixel, uint32_t sample, uint32_t site,
+                                                           uint32_t g, uint32_t k0, uint32_t k1, int lane) {
+    const uint64_t m = ballot(need);
+    const int n = __popcll(m);
+    if (n > 4) return false;
+    // the owners' lanes, in rank order (wave-uniform: scalar arithmetic); ranks without an owner name the first one
+    const int l0 = __builtin_ctzll(m);
+    const uint64_t m1 = m & (m - 1ull);
+    const int l1 = m1 ? __builtin_ctzll(m1) : l0;
+    const uint64_t m2 = m1 & (m1 - 1ull);
+    const int l2 = m2 ? __builtin_ctzll(m2) : l0;
+    const uint64_t m3 = m2 & (m2 - 1ull);
+    const int l3 = m3 ? __builtin_ctzll(m3) : l0;
+    const int q = lane >> 4;  // the rank this lane serves
+    const int owner = q == 0 ? l0 : q == 1 ? l1 : q == 2 ? l2 : l3;
+    const uint32_t c0 = lane_pull(owner, pixel), c1 = lane_pull(owner, sample), c2 = lane_pull(owner, site);
+    const int j = lane & 15, role = j & 3;
+    const uint32_t index = 3u * (g + (uint32_t)(j >> 2)) + (uint32_t)(role < 3 ? role : 2);
+    const u32x4 b = philox4x32_10(c0, c1, c2, index, k0, k1);
+    const uint32_t w3 = lane_pull(lane - 3, b.w), w2 = lane_pull(lane - 2, b.w), w1 = lane_pull(lane - 1, b.w);
+    const uint32_t x = role == 3 ? w3 : b.x, y = role == 3 ? w2 : b.y, z = role == 3 ? w1 : b.z;
+    const uint64_t passed = ballot(q < n && inside_unit_sphere(x, y, z));
+    // an owner looks at the sixteen attempts made for it
+    const int base = (int)rank_below(m) << 4;
+    const uint32_t mine = need ? (uint32_t)(passed >> base) & 0xFFFFu : 0u;
+    const int from = mine != 0u ? base + __builtin_ctz(mine) : lane;
+    const uint32_t px = lane_pull(from, x), py = lane_pull(from, y), pz = lane_pull(from, z);
+    if (mine != 0u) {
+        need = false;
+        p.kx = px;
+        p.ky = py;
+        p.kz = pz;
+    }
+    return true;
+}
+#endif
+
 // random_in_unit_sphere (B1/vec3.h:114-120) for the lanes with need == true, the blocks beyond block0 coming from
 // philox_blocks_for_lanes: blocks 1 and 2 (attempts 1 to 3) in one evaluation, then three per evaluation (four attempts).
 // Same draws as random_in_unit_sphere below.  All 64 lanes must call it.
@@ -262,6 +312,12 @@ __device__ __forceinline__ d3 random_in_unit_sphere_for_lanes(bool need, u32x4 b
         if (ballot(need) != 0ull) attempt(block0.w, b[0].w, b[1].w);
     }
     for (uint32_t g = 1; ballot(need) != 0ull; ++g) {
+#if RT_INTEGER_SPHERE_TEST && RT_SPHERE_ATTEMPTS_BY_HELPERS
+        if (sphere_attempts_by_helpers(need, p, pixel, sample, site, g, k0, k1, lane)) {
+            g += 3u;  // groups g .. g+3 are done
+            continue;
+        }
+#endif
         u32x4 b[3];
         philox_blocks_for_lanes<3>(need, pixel, sample, site, 3u * g, 0u, k0, k1, lane, owners, b);
         attempt(b[0].x, b[0].y, b[0].z);
