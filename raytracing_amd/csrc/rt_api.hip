@@ -1352,6 +1352,7 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
         A.max_depth = p->max_depth;
         A.item_cap = item_cap;
         A.pixel_pass = pixel_pass ? 1 : 0;
+        A.plan = plan;
         A.n_items = (uint32_t)items;
         A.key0 = (uint32_t)p->seed;
         A.key1 = (uint32_t)(p->seed >> 32);

@@ -153,6 +153,15 @@ inline WidthDivider make_width_divider(int32_t width) {
     return d;
 }
 
+// How the samples of a frame are cut into work items (make_item_plan, rt_render_common.h).
+struct ItemPlan {
+    int32_t cap, K, R, levels;
+    uint32_t npix;
+    uint32_t bulk_items;  // pixel-by-pixel plan: npix * levels (every item); else 0
+    uint32_t batch;       // items a wave takes from the queue at a time, at most 64
+    int32_t exclusive;    // 1: every item of a pixel goes to the same wave (whole pixels per batch)
+};
+
 struct RenderArgs {
     SphereListDev scene;
     CameraDev cam;
@@ -163,6 +172,7 @@ struct RenderArgs {
     int32_t max_depth;
     int32_t item_cap;       // longest run of samples of one pixel that forms a work item (see ItemPlan)
     int32_t pixel_pass;     // 1: runs are numbered pixel by pixel and summed in the accumulation cache (ItemPlan)
+    ItemPlan plan;          // make_item_plan(sample_count, item_cap, width * height, pixel_pass), worked out by the host
     uint32_t n_items;       // number of work items
     uint32_t key0, key1;    // Philox key
     int32_t exact_only;     // 1: skip the float screen, test every sphere in double (validation)

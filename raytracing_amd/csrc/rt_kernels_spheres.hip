@@ -96,8 +96,6 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     }
     const double* frame_rcp = s_frame_rcp[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
-    const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;
-    const ItemPlan plan = make_item_plan(A.sample_count, A.item_cap, npix, A.pixel_pass != 0);
     __shared__ AccumCache s_acc[4];
     constexpr bool WAVE_BLOCKS = (!TIMED || RT_TIMED_WAVE_BLOCKS != 0) && (RT_COOP_SHADE != 0);  // Philox blocks of the rejection loops computed wave-wide
     accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
@@ -109,7 +107,10 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     double tm = 0.0;  // ray::time(), the same for every segment of a path (TIMED only)
     LaneWork w{};
     WaveWork wq{};
-    const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6], plan.batch, plan.exclusive};
+#if !RT_ARGS_FROM_MEMORY
+    const ItemPlan plan = A.plan;
+    const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6], plan.batch, plan.exclusive != 0};
+#endif
     // statistics of the wave (counted with population counts of lane masks: scalar registers, not one per lane)
     uint32_t n_samples = 0, n_rays = 0;
     uint32_t n_bad = 0, n_overflow = 0;  // per lane: rare events counted where they happen
@@ -132,6 +133,9 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
         asm volatile("" : "+s"(args_in_memory));
         const RenderArgs& A = *(const RenderArgs*)args_in_memory;  // (the loads stay scalar: the address space is inferred)
         const SphereListDev& S = A.scene;
+        // (the item plan and the queue's description likewise: read where refill_work uses them)
+        const ItemPlan& plan = A.plan;
+        const WorkQueues Q{A.item_counter, A.n_items, A.accum, &s_acc[threadIdx.x >> 6], plan.batch, plan.exclusive != 0};
 #endif
         // ---- refill: finish items, take new ones, start the next sample
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
@@ -279,7 +283,10 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
         pc.mark(SEC_SHADE);
     }
 
-    accum_cache_flush(Q, lane);
+    {
+        const WorkQueues Q{A_in.item_counter, A_in.n_items, A_in.accum, &s_acc[threadIdx.x >> 6], A_in.plan.batch, A_in.plan.exclusive != 0};
+        accum_cache_flush(Q, lane);
+    }
 #ifdef RT_TAIL_PROBE
     if (lane == 0 && A.probe) {
         uint64_t* w = A.probe + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));

@@ -381,13 +381,7 @@ __device__ __forceinline__ void add_i64_own(int64_t* p, int64_t v) { *p += v; }
 // the wave's accumulation cache (below) and reach memory once per pixel instead of once per run.  (Ending this queue in
 // fine grains as well -- one-sample items, or halved runs of every n-th pixel, after the long runs -- was measured and
 // changes nothing: the waves balance their own ends, see refill_work.)
-struct ItemPlan {
-    int32_t cap, K, R, levels;
-    uint32_t npix;
-    uint32_t bulk_items;  // pixel-by-pixel plan: npix * levels (every item); else 0
-    uint32_t batch;       // items a wave takes from the queue at a time, at most 64
-    bool exclusive;       // every item of a pixel goes to the same wave (whole pixels per batch)
-};
+// (struct ItemPlan: rt_internal.h, beside the kernel arguments that carry it)
 __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap, uint32_t npix, bool pixel_pass) {
     ItemPlan p;
     p.cap = cap < 1 ? 1 : cap;
@@ -398,15 +392,15 @@ __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t ca
     if (pixel_pass) {
         p.levels = p.K + (p.R > 0 ? 1 : 0);
         p.bulk_items = npix * (uint32_t)p.levels;
-        p.exclusive = p.levels >= 1 && p.levels <= 64;
-        p.batch = p.exclusive ? (uint32_t)((64 / p.levels) * p.levels) : 64u;
+        p.exclusive = (p.levels >= 1 && p.levels <= 64) ? 1 : 0;
+        p.batch = p.exclusive != 0 ? (uint32_t)((64 / p.levels) * p.levels) : 64u;
     } else {
         int bits = 0;
         for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
         p.levels = p.K + bits;
         p.bulk_items = 0u;
         p.batch = 64u;
-        p.exclusive = false;
+        p.exclusive = 0;
     }
     return p;
 }
