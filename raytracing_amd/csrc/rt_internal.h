@@ -153,9 +153,36 @@ inline WidthDivider make_width_divider(int32_t width) {
     return d;
 }
 
+// n / d for every 32-bit n (Granlund and Montgomery's round-up form): t = high word of n * mul,
+// q = (t + ((n - t) >> sh1)) >> sh2 -- five vector instructions where the division itself takes about twenty-five.
+struct U32Divider {
+    uint32_t mul, sh1, sh2;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline U32Divider make_u32_divider(uint32_t d) {
+    if (d == 0u) d = 1u;
+    uint32_t l = 0;
+    while (l < 32u && ((uint64_t)1 << l) < (uint64_t)d) ++l;
+    U32Divider v;
+    v.mul = (uint32_t)(((((uint64_t)1 << l) - (uint64_t)d) << 32) / (uint64_t)d + 1u);
+    v.sh1 = l < 1u ? l : 1u;
+    v.sh2 = l < 1u ? 0u : l - 1u;
+    return v;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t div_u32(uint32_t n, const U32Divider& v) {
+    const uint32_t t = (uint32_t)(((uint64_t)n * (uint64_t)v.mul) >> 32);
+    return (t + ((n - t) >> v.sh1)) >> v.sh2;
+}
+
 // How the samples of a frame are cut into work items (make_item_plan, rt_render_common.h).
 struct ItemPlan {
     int32_t cap, K, R, levels;
+    U32Divider by_levels, by_npix;  // item number -> pixel (pixel-by-pixel plan) or level (frame-by-frame plan)
     uint32_t npix;
     uint32_t bulk_items;  // pixel-by-pixel plan: npix * levels (every item); else 0
     uint32_t batch;       // items a wave takes from the queue at a time, at most 64

@@ -402,6 +402,8 @@ __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t ca
         p.batch = 64u;
         p.exclusive = 0;
     }
+    p.by_levels = make_u32_divider((uint32_t)(p.levels > 0 ? p.levels : 1));
+    p.by_npix = make_u32_divider(npix);
     return p;
 }
 __host__ __device__ inline uint64_t item_count(const ItemPlan& p, uint32_t npix) {
@@ -410,13 +412,21 @@ __host__ __device__ inline uint64_t item_count(const ItemPlan& p, uint32_t npix)
 // item number -> pixel and samples [first, first + count), relative to the first sample of the call
 __device__ __forceinline__ void item_lookup(const ItemPlan& p, uint32_t item, uint32_t& pixel, int& first, int& count) {
     if (p.bulk_items != 0u) {
+#if RT_ISSUE_BOUND  // (the scene-graph kernels keep the division: the dividers' registers cost their final-scene variant 5 %)
+        pixel = div_u32(item, p.by_levels);
+#else
         pixel = item / (uint32_t)p.levels;
+#endif
         const int level = (int)(item - pixel * (uint32_t)p.levels);
         first = level * p.cap;
         count = level < p.K ? p.cap : p.R;
         return;
     }
+#if RT_ISSUE_BOUND
+    const uint32_t l = div_u32(item, p.by_npix);
+#else
     const uint32_t l = item / p.npix;
+#endif
     pixel = item - l * p.npix;
     const int level = (int)l;
     if (level < p.K) {
