@@ -458,7 +458,14 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
         }
         // A dielectric has no albedo (its attenuation is white, B1/material.h:59); the slot carries 1.0 / ir, the
         // refraction ratio of a front-face hit (B1/material.h:60), so that no lane divides for it
-        if (m.kind == RT_MAT_DIELECTRIC) md.ax = 1.0 / m.param;
+        // and ay, az Schlick's r0 = ((1 - x) / (1 + x))^2 (B1/material.h:85-86) for the two ratios a ray can meet,
+        // x = 1 / ir (front face) and x = ir
+        if (m.kind == RT_MAT_DIELECTRIC) {
+            md.ax = 1.0 / m.param;
+            const double f = (1 - md.ax) / (1 + md.ax), b = (1 - m.param) / (1 + m.param);
+            md.ay = f * f;
+            md.az = b * b;
+        }
         mats[i] = md;
     }
     return mats;

@@ -35,7 +35,7 @@ struct SphereMotion {
 struct MaterialDev {
     int32_t kind;  // RT_MAT_*
     int32_t tex;   // texture index of lambertian / diffuse_light / isotropic (general scenes), else -1
-    double ax, ay, az;  // albedo (lambertian with a solid texture, metal); dielectric: ax = 1.0 / ir
+    double ax, ay, az;  // albedo (lambertian with a solid texture, metal); dielectric: ax = 1.0 / ir, ay and az = Schlick's r0 for the ratios 1 / ir and ir
     double param;       // fuzz / ir
 };
 

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
                     const double cos_theta = fmin(dot(-unit_direction, normal), 1.0);
                     const double sin_theta = SHORT ? sqrt_shared(1.0 - cos_theta * cos_theta) : sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
-                    if (!do_reflect) do_reflect = reflectance(cos_theta, refraction_ratio) > u01(block0.x);
+                    if (!do_reflect) do_reflect = reflectance_from_r0(cos_theta, front_face ? m.ay : m.az) > u01(block0.x);  // r0: device_materials
                     nd = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
                 }
                 if (!done) {

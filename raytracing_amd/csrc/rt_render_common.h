@@ -328,6 +328,12 @@ __device__ __forceinline__ d3 random_in_unit_sphere_for_lanes(bool need, u32x4 b
     return point();
 }
 
+// reflectance for an r0 = ((1 - ref_idx) / (1 + ref_idx))^2 (B1/material.h:85-86) worked out before: B1/material.h:87
+__device__ __forceinline__ double reflectance_from_r0(double cosine, double r0) {
+    const double x = 1 - cosine;
+    const double x2 = x * x;
+    return r0 + (1 - r0) * (x2 * x2 * x);  // pow(x, 5) by multiplication (<= 2 ulp from libm pow)
+}
 __device__ __forceinline__ double reflectance(double cosine, double ref_idx) {  // B1/material.h:83-88
     double r0 = (1 - ref_idx) / (1 + ref_idx);
     r0 = r0 * r0;
