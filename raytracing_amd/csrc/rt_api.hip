@@ -634,11 +634,11 @@ static int build_sphere_set(rt_context* ctx, const rt_scene_desc* sc, const std:
         const rt_node& nd = sc->nodes[prims[(size_t)i]];
         double cx = nd.p[0], cy = nd.p[1], cz = nd.p[2], r = nd.p[3];
         exact[i] = SphereExact{cx, cy, cz, r};
-        if (timed) motion[i] = SphereMotion{cx, cy, cz, 0.0, 1.0, 0};
+        if (timed) motion[i] = SphereMotion{0.0, 0.0, 0.0, 0, 0.0, 1.0};
         if (nd.kind == RT_NODE_MOVING_SPHERE) {  // p = centre0, centre1, time0, time1, radius
             const double dx = nd.p[3] - cx, dy = nd.p[4] - cy, dz = nd.p[5] - cz;
             exact[i].radius = nd.p[8];
-            motion[i] = SphereMotion{nd.p[3], nd.p[4], nd.p[5], nd.p[6], nd.p[7], 1};
+            motion[i] = SphereMotion{dx, dy, dz, (nd.p[6] == 0.0 && nd.p[7] == 1.0) ? 1 : 2, nd.p[6], nd.p[7]};
             sweep_lo = std::max(sweep_lo, nd.p[6]);
             sweep_hi = std::min(sweep_hi, nd.p[7]);
             // every centre(t), t in [time0, time1], lies on the segment centre0..centre1 (up to a few ulps): bound it by

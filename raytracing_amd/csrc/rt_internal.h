@@ -28,9 +28,9 @@ struct SphereExact {
 // sphere that bounds its sweep over [time0, time1].
 struct TextureDev;
 struct SphereMotion {
-    double c1x, c1y, c1z;  // centre at time1 (B2/moving_sphere.h:13-16); the SphereExact centre is the one at time0
-    double time0, time1;
-    int64_t moving;        // 0: static sphere, the other members are unused
+    double vx, vy, vz;     // center1 - center0 (B2/moving_sphere.h:28; the SphereExact centre is center0), from the upload
+    int64_t moving;        // 0: static sphere (the other members are unused), 1: moving over [0, 1], 2: over [time0, time1]
+    double time0, time1;   // read only when moving == 2
 };
 struct MaterialDev {
     int32_t kind;  // RT_MAT_*

@@ -265,8 +265,16 @@ template <bool TIMED>
 __device__ __forceinline__ d3 center_at(const SphereSetDev& S, int j, const SphereExact& e, double tm) {
     d3 center{e.cx, e.cy, e.cz};
     if constexpr (TIMED) {
-        const SphereMotion mv = S.motion[j];
-        if (mv.moving != 0) center = center + motion_fraction(tm, mv.time0, mv.time1) * (d3{mv.c1x, mv.c1y, mv.c1z} - center);
+        const SphereMotion* mv = S.motion + j;
+        const d3 travel{mv->vx, mv->vy, mv->vz};
+        const int64_t moving = mv->moving;
+        if (moving != 0) {
+            // (time - time0) / (time1 - time0): over [0, 1] -- the interval every moving sphere of the reference has -- the
+            // quotient is `time` itself, bit for bit (time - 0 = time, 1 - 0 = 1, time / 1 = time)
+            double fraction = tm;
+            if (moving == 2) fraction = (tm - mv->time0) / (mv->time1 - mv->time0);
+            center = center + fraction * travel;
+        }
     }
     return center;
 }
