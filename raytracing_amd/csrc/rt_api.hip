@@ -1325,7 +1325,8 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
                          : (importance ? render_scene_blocks_per_cu(ctx->graph.features, true) : ctx->blocks_per_cu_scene);
     if (ctx->blocks_override) per_cu = ctx->blocks_override;
     int blocks = ctx->num_cus * per_cu;
-    const int64_t max_useful = (items + 255) / 256;
+    const int wg_threads = spheres ? RT_SPHERES_WG : 256;
+    const int64_t max_useful = (items + wg_threads - 1) / wg_threads;
     if (blocks > max_useful) blocks = (int)max_useful;
     if (blocks < 1) blocks = 1;
 

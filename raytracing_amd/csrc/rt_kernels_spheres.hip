@@ -68,16 +68,17 @@ __device__ __forceinline__ d3 sphere_world_texture(const SphereListDev& S, int t
 }
 
 template <bool TIMED>
-__global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A_in) {
+__global__ void __launch_bounds__(RT_SPHERES_WG, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A_in) {
+    constexpr int WG_WAVES = RT_SPHERES_WG / 64;
     const RenderArgs& A = A_in;
-    __shared__ uint16_t s_list[4][CAND_CAP * 64];
-    __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
+    __shared__ uint16_t s_list[WG_WAVES][CAND_CAP * 64];
+    __shared__ uint32_t s_rows[WG_WAVES][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
     uint32_t* rows = s_rows[threadIdx.x >> 6];
     // The camera (21 doubles) is needed once per sample; read from the kernel arguments it would sit in 42 scalar
     // registers for the whole kernel.  One copy per wave in LDS, read back where it is used.
-    __shared__ CameraDev s_cam[4];
+    __shared__ CameraDev s_cam[WG_WAVES];
     {
         const double* src = (const double*)&A.cam;
         double* dst = (double*)&s_cam[threadIdx.x >> 6];
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     }
     const CameraDev& cam = s_cam[threadIdx.x >> 6];
     // reciprocals of the jitter's two divisors (shared_divisor), one copy per wave like the camera
-    __shared__ double s_frame_rcp[4][2];
+    __shared__ double s_frame_rcp[WG_WAVES][2];
     {
         double* rcp = s_frame_rcp[threadIdx.x >> 6];
         if (lane < 2) rcp[lane] = shared_divisor(lane == 0 ? A.width_m1 : A.height_m1).r;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     }
     const double* frame_rcp = s_frame_rcp[threadIdx.x >> 6];
     const SphereListDev& S = A.scene;
-    __shared__ AccumCache s_acc[4];
+    __shared__ AccumCache s_acc[WG_WAVES];
     constexpr bool WAVE_BLOCKS = (!TIMED || RT_TIMED_WAVE_BLOCKS != 0) && (RT_COOP_SHADE != 0);  // Philox blocks of the rejection loops computed wave-wide
     accum_cache_init(&s_acc[threadIdx.x >> 6], lane);
 
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(256, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES
     }
 #ifdef RT_TAIL_PROBE
     if (lane == 0 && A.probe) {
-        uint64_t* w = A.probe + 16ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        uint64_t* w = A.probe + 16ull * (blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6));
         for (int k = 0; k < 8; ++k) w[8 + k] = pc.sec[k];
         w[0] = pr_t0;
         w[1] = pr_tq;
@@ -349,8 +350,8 @@ __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A)
 }
 
 hipError_t launch_render_spheres(const RenderArgs& args, bool timed, int blocks, hipStream_t stream) {
-    if (timed) hipLaunchKernelGGL(k_render_spheres<true>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(k_render_spheres<false>, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+    if (timed) hipLaunchKernelGGL(k_render_spheres<true>, dim3((unsigned)blocks), dim3(RT_SPHERES_WG), 0, stream, args);
+    else hipLaunchKernelGGL(k_render_spheres<false>, dim3((unsigned)blocks), dim3(RT_SPHERES_WG), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -363,8 +364,8 @@ hipError_t launch_first_hit_spheres(const FirstHitArgs& args, bool timed, hipStr
 
 int render_spheres_blocks_per_cu(bool timed) {
     int n = 0;
-    const hipError_t e = timed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<true>, 256, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<false>, 256, 0);
+    const hipError_t e = timed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<true>, RT_SPHERES_WG, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render_spheres<false>, RT_SPHERES_WG, 0);
     if (e != hipSuccess || n < 1) n = 2;
     return n;
 }
