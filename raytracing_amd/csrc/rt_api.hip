@@ -38,7 +38,7 @@ struct rt_context {
     bool graph_can_importance = false;  // the uploaded world has light shapes and no isotropic material
     // sphere-list launches with at least this many samples per pixel use the pixel-by-pixel pass (measured
     // crossover on config 2: slower by 0.5 ms at 32 spp, faster by 1.8 ms at 500 spp)
-    int pixel_pass_min_samples = 100;
+    int pixel_pass_min_samples = 48;
     int blocks_override = 0;
     std::string detail;
     bool exact_only = false;     // validation: bypass the float screen
@@ -1292,9 +1292,23 @@ static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const r
     return RT_OK;
 }
 
-// Longest run of samples of one pixel handed to a lane as one work item (RT_ITEM_SAMPLES overrides).
-static int item_cap_for(const rt_render_params*) {
+// Longest run of samples of one pixel handed to a lane as one work item (RT_ITEM_SAMPLES overrides).  Eight by default.
+// The pixel-by-pixel plan gives a wave whole pixels, floor(64 / runs per pixel) of them at a time, so the runs per pixel
+// (= floor(samples / cap)) decide how many of its 64 lanes a batch fills: a cap between 8 and 32 that makes them 64, 32,
+// 16, 8 or 4 fills them all, and longer runs mean fewer items to fetch and finish (500 samples: 31 -> 16 runs, 68.1
+// against 69.1 ms with runs of 8; 250 samples: 15 -> 16 runs, 34.3 against 34.5 ms; bouncing spheres at 1000 samples:
+// 31 -> 32 runs, 149.2 against 151.1 ms).  Sums do not depend on the partition (fixed point).
+static int item_cap_for(const rt_render_params* p, bool pixel_pass) {
     int cap = 8;
+    if (pixel_pass && p->sample_count >= 200) {  // (below that, longer runs lengthen the launch's tail by what they save)
+        for (int runs = 64; runs >= 4; runs /= 2) {
+            const int c = p->sample_count / runs;
+            if (c >= 8 && c <= 32 && p->sample_count / c == runs) {
+                cap = c;
+                break;
+            }
+        }
+    }
     if (const char* s = std::getenv("RT_ITEM_SAMPLES")) {
         int v = std::atoi(s);
         if (v >= 1) cap = v;
@@ -1308,11 +1322,12 @@ static int item_cap_for(const rt_render_params*) {
 static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed,
                           uint32_t* d_counter, uint64_t* d_stats, bool timed) {
 
-    const int item_cap = item_cap_for(p);
     const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
     const bool spheres = use_sphere_kernels(ctx, cam->time0, cam->time1);
-    // the pixel-by-pixel pass pays off from about a hundred samples per pixel (RT_PIXEL_PASS=0/1 overrides)
+    // the pixel-by-pixel pass pays off from about fifty samples per pixel (63: 9.06 against 9.39 ms with three frames in
+    // flight, 9.85 against 9.86 alone; 32: 4.66 against 4.90 and 5.48 against 5.33; RT_PIXEL_PASS=0/1 overrides)
     bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
+    const int item_cap = item_cap_for(p, pixel_pass);
     const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, pixel_pass);
     const int64_t items = (int64_t)item_count(plan, npix);
     // (room above the last item for the one batch every wave still adds to the queue head when it finds it dry)
