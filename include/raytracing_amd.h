@@ -244,6 +244,11 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
 int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,
                      int64_t* d_accum_fixed);
 int rt_context_synchronize(rt_context* ctx);
+/* Whether rt_render_device would accept these arguments on this context (RT_OK, or the code and detail it would
+ * return), without enqueuing anything: every refusal rt_render_device can make short of a HIP runtime error.  A
+ * caller that must not start a frame it cannot finish everywhere (rt_group_render_async: its peers would wait in the
+ * all-reduce) asks first.  The reference has no counterpart: its loop bounds are literals (B1/RayTracing.cpp:82-86). */
+int rt_render_check(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params);
 /* The hand-over of the sums to write_color (B1/RayTracing.cpp:125: `write_color(std::cout, pixel_color, ...)`) for a
  * frame that rt_render_device left on the device: waits for the context's stream, converts the fixed-point sums
  * d_accum_fixed[3*width*height] (DEVICE memory) to doubles on the device and copies them to the HOST array
@@ -340,9 +345,27 @@ int rt_group_render(rt_group* g, const rt_camera_desc* cam, const rt_render_para
  * the all-reduce, all enqueued on the slot's streams.  rt_group_wait blocks until the slot's summed frame is
  * complete on every local member; rt_group_read then hands it over as rt_read_sums does (from local member 0);
  * rt_group_device_sums is the buffer itself (DEVICE memory of that member's GPU, valid until the slot's next frame
- * or rt_group_destroy).  A slot must be waited for before it is given another frame. */
+ * or rt_group_destroy).  A slot must be waited for before it is given another frame.
+ *
+ * Failures and the collective.  Everything that can be refused (arguments, no world, limits: rt_render_check) is
+ * checked for every local member, and the slot's buffers are grown, BEFORE anything is enqueued: such an error means
+ * that nothing was started, and since all processes make the same call on the same world it is returned on all of
+ * them.  If a member's enqueue fails after that (a HIP runtime error), the call still joins the all-reduce with every
+ * member -- no peer is left waiting in it -- and returns the error; the failed member's share is missing from the
+ * sums, and a failure word that travels through the all-reduce behind the sums makes rt_group_wait return RT_ERR_COMM
+ * for that frame on EVERY rank.  The group stays usable.  Only an error of the all-reduce itself (RT_ERR_COMM from
+ * this call) leaves the communicator unusable: destroy the group.
+ * The slots of a member share one communicator; the all-reduces of successive frames are ordered across the slots'
+ * streams by an event each records and the next one waits for, in the order the frames were submitted (the same on
+ * every rank). */
 int rt_group_render_async(rt_group* g, const rt_camera_desc* cam, const rt_render_params* params, int slot);
 int rt_group_wait(rt_group* g, int slot);
+/* Allocates the accumulation buffers of every slot for frames of width x height now, so that rt_group_render_async
+ * only enqueues work (it grows them itself otherwise, on a frame's first use of a slot, before anything is started). */
+int rt_group_reserve(rt_group* g, int width, int height);
+/* Validation switch: the next rt_group_render_async treats local member `local_index` as if its kernel launch had
+ * failed with a HIP error (exercises the path above on a healthy machine). */
+int rt_group_set_fail_next(rt_group* g, int local_index);
 int rt_group_read(rt_group* g, int slot, double* accum_rgb_out);
 const int64_t* rt_group_device_sums(rt_group* g, int local_index, int slot);
 /* Statistics of the local members since the last call (sums over members and slots; synchronises them). */

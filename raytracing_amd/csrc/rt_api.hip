@@ -1423,6 +1423,25 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
     return RT_OK;
 }
 
+// What enqueue_render refuses, without enqueuing anything.
+static int check_launch(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p) {
+    if (p->sample_count == 0 || p->max_depth <= 0) return RT_OK;  // nothing is launched
+    const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
+    const bool spheres = use_sphere_kernels(ctx, cam->time0, cam->time1);
+    const bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
+    const ItemPlan plan = make_item_plan(p->sample_count, item_cap_for(p, pixel_pass), npix, pixel_pass);
+    if ((int64_t)item_count(plan, npix) > 0xFF000000ll) return fail(ctx, RT_ERR_LIMIT, "more than 2^32 work items; raise RT_ITEM_SAMPLES");
+    if ((p->flags & RT_RENDER_IMPORTANCE) != 0 && (spheres || !ctx->graph_can_importance))
+        return fail(ctx, RT_ERR_UNSUPPORTED_SCENE,
+                    "RT_RENDER_IMPORTANCE needs a world uploaded with light shapes (lights_plus1) and without isotropic materials");
+    return RT_OK;
+}
+
+int rt_render_check(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p) {
+    const int rc = check_render_args(ctx, cam, p);
+    return rc != RT_OK ? rc : check_launch(ctx, cam, p);
+}
+
 int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* p, int64_t* d_accum_fixed) {
     int rc = check_render_args(ctx, cam, p);
     if (rc != RT_OK) return rc;

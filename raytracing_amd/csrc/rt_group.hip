@@ -65,17 +65,27 @@ const Rccl* rccl() {
     return g_rccl.handle ? &g_rccl : nullptr;
 }
 
+// The buffer of a slot holds the frame's 3 W H sums and, behind them, one more word that travels through the same
+// all-reduce: the number of members, over all processes, that could not enqueue their share of the frame.  Every rank
+// therefore learns from its own copy whether the summed frame is whole.
 struct Slot {
     hipStream_t stream = nullptr;
     rt_context* ctx = nullptr;
     int64_t* d_accum = nullptr;
-    size_t elems = 0;
+    size_t elems = 0;           // capacity in sums (the buffer holds elems + 1 words)
+    int64_t* h_failed = nullptr;  // pinned: the frame's failure word, copied behind the all-reduce
     int width = 0, height = 0;  // of the frame the slot holds
 };
 struct Member {
     int device = -1;
     ncclComm_t comm = nullptr;
     std::vector<Slot> slots;
+    // Collectives of one communicator must run in the order they were issued, on every rank.  The slots of a member
+    // share its communicator but have streams of their own, so the order is made explicit: every all-reduce records
+    // this event behind itself, and the next one -- whichever slot's stream it is on -- waits for it first.
+    hipEvent_t last_collective = nullptr;
+    bool collective_pending = false;
+    bool fail_next = false;  // validation: rt_group_set_fail_next
 };
 
 thread_local std::string g_group_create_detail;
@@ -122,8 +132,11 @@ int make_members(rt_group* g) {
     for (Member& m : g->members) {
         G_HIP(nullptr, hipSetDevice(m.device));
         m.slots.resize((size_t)g->frame_slots);
+        G_HIP(nullptr, hipEventCreateWithFlags(&m.last_collective, hipEventDisableTiming));
         for (Slot& s : m.slots) {
             G_HIP(nullptr, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            G_HIP(nullptr, hipHostMalloc((void**)&s.h_failed, sizeof(int64_t), hipHostMallocDefault));
+            *s.h_failed = 0;
             const int rc = rt_context_create(m.device, (void*)s.stream, &s.ctx);
             if (rc != RT_OK) return gfail(nullptr, rc, std::string("rt_context_create: ") + rt_last_error_detail(nullptr));
         }
@@ -132,6 +145,24 @@ int make_members(rt_group* g) {
 }
 
 bool slot_ok(const rt_group* g, int slot) { return slot >= 0 && slot < g->frame_slots; }
+
+// Room for a frame of `elems` sums in the slot's buffer of every local member.  Waits for the slot's stream before a
+// buffer is replaced.
+int reserve_slot(rt_group* g, int slot, size_t elems) {
+    for (Member& m : g->members) {
+        Slot& s = m.slots[(size_t)slot];
+        if (s.elems >= elems) continue;
+        G_HIP(g, hipSetDevice(m.device));
+        G_HIP(g, hipStreamSynchronize(s.stream));
+        (void)hipFree(s.d_accum);
+        s.d_accum = nullptr;
+        s.elems = 0;
+        s.width = s.height = 0;
+        G_HIP(g, hipMalloc((void**)&s.d_accum, (elems + 1) * sizeof(int64_t)));
+        s.elems = elems;
+    }
+    return RT_OK;
+}
 
 }  // namespace
 
@@ -175,8 +206,10 @@ void rt_group_destroy(rt_group* g) {
         for (Slot& s : m.slots) {
             if (s.ctx) rt_context_destroy(s.ctx);  // waits for the stream, which the context does not own
             (void)hipFree(s.d_accum);
+            if (s.h_failed) (void)hipHostFree(s.h_failed);
             if (s.stream) (void)hipStreamDestroy(s.stream);
         }
+        if (m.last_collective) (void)hipEventDestroy(m.last_collective);
     }
     delete g;
 }
@@ -265,6 +298,30 @@ int rt_group_scene_upload(rt_group* g, const rt_scene_desc* scene) {
     return RT_OK;
 }
 
+int rt_group_reserve(rt_group* g, int width, int height) {
+    if (!g) return RT_ERR_INVALID_ARGUMENT;
+    if (width < 2 || height < 2 || (int64_t)width * height > (int64_t)1 << 28) return gfail(g, RT_ERR_INVALID_ARGUMENT, "bad frame size");
+    for (int slot = 0; slot < g->frame_slots; ++slot) {
+        const int rc = reserve_slot(g, slot, (size_t)3 * width * height);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
+int rt_group_set_fail_next(rt_group* g, int local_index) {
+    if (!g || local_index < 0 || local_index >= (int)g->members.size()) return RT_ERR_INVALID_ARGUMENT;
+    g->members[(size_t)local_index].fail_next = true;
+    return RT_OK;
+}
+
+// A frame in three steps, so that a failure never leaves a peer waiting in the all-reduce:
+//   1. everything that can be refused is checked, and every buffer grown, for ALL local members before anything is
+//      enqueued: a call that returns an error from this step has enqueued nothing and joined nothing, and because every
+//      process of the group makes the same call with the same arguments on the same world, it fails on all of them;
+//   2. every member zeroes its buffer and enqueues its kernel.  A member whose enqueue fails now (a HIP error) is
+//      remembered, its share is missing, and the frame's failure word in its buffer is set;
+//   3. EVERY member joins the all-reduce regardless, the failure word travels with the sums, and each slot copies its
+//      word to the host behind the collective.  rt_group_wait reports a frame whose word is not zero on every rank.
 int rt_group_render_async(rt_group* g, const rt_camera_desc* cam, const rt_render_params* p, int slot) {
     if (!g) return RT_ERR_INVALID_ARGUMENT;
     if (!cam || !p || !slot_ok(g, slot)) return gfail(g, RT_ERR_INVALID_ARGUMENT, "null camera or params, or bad slot");
@@ -272,39 +329,76 @@ int rt_group_render_async(rt_group* g, const rt_camera_desc* cam, const rt_rende
         return gfail(g, RT_ERR_INVALID_ARGUMENT, "bad frame size or sample count");
     const Rccl* R = rccl();
     const size_t elems = (size_t)3 * p->width * p->height;
+    // ---- step 1
+    std::vector<rt_render_params> share(g->members.size(), *p);
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        int begin = 0, count = 0;
+        rt_split_samples(p->sample_count, g->first_rank + (int)i, g->n_ranks, &begin, &count);
+        share[i].sample_begin = p->sample_begin + begin;
+        share[i].sample_count = count;
+        rt_context* ctx = g->members[i].slots[(size_t)slot].ctx;
+        // (the whole frame's range is checked as well: a member with fewer samples must not pass where another fails)
+        int rc = rt_render_check(ctx, cam, p);
+        if (rc == RT_OK) rc = rt_render_check(ctx, cam, &share[i]);
+        if (rc != RT_OK) return gfail_ctx(g, rc, ctx, "rt_render_check");
+    }
+    {
+        const int rc = reserve_slot(g, slot, elems);
+        if (rc != RT_OK) return rc;
+    }
+    // ---- step 2
+    int first_rc = RT_OK;
+    std::string first_detail;
+    auto remember = [&](int rc, const std::string& what) {
+        if (first_rc == RT_OK) {
+            first_rc = rc;
+            first_detail = what;
+        }
+    };
     for (size_t i = 0; i < g->members.size(); ++i) {
         Member& m = g->members[i];
         Slot& s = m.slots[(size_t)slot];
-        G_HIP(g, hipSetDevice(m.device));
-        if (s.elems < elems) {
-            G_HIP(g, hipStreamSynchronize(s.stream));
-            (void)hipFree(s.d_accum);
-            s.d_accum = nullptr;
-            s.elems = 0;
-            G_HIP(g, hipMalloc((void**)&s.d_accum, elems * sizeof(int64_t)));
-            s.elems = elems;
-        }
         s.width = s.height = 0;  // the slot holds no frame until this one is enqueued in full
-        G_HIP(g, hipMemsetAsync(s.d_accum, 0, elems * sizeof(int64_t), s.stream));
-        rt_render_params mine = *p;
-        int begin = 0, count = 0;
-        rt_split_samples(p->sample_count, g->first_rank + (int)i, g->n_ranks, &begin, &count);
-        mine.sample_begin = p->sample_begin + begin;
-        mine.sample_count = count;
-        const int rc = rt_render_device(s.ctx, cam, &mine, s.d_accum);  // a member with no samples enqueues nothing
-        if (rc != RT_OK) return gfail_ctx(g, rc, s.ctx, "rt_render_device");
+        hipError_t e = hipSetDevice(m.device);
+        if (e == hipSuccess) e = hipMemsetAsync(s.d_accum, 0, (elems + 1) * sizeof(int64_t), s.stream);
+        int rc = e == hipSuccess ? RT_OK : RT_ERR_HIP;
+        if (rc != RT_OK) remember(rc, std::string("zeroing the frame: ") + hipGetErrorString(e));
+        if (rc == RT_OK && m.fail_next) {
+            m.fail_next = false;
+            rc = RT_ERR_HIP;
+            remember(rc, "member " + std::to_string(g->first_rank + (int)i) + ": failure requested by rt_group_set_fail_next");
+        } else if (rc == RT_OK) {
+            rc = rt_render_device(s.ctx, cam, &share[i], s.d_accum);  // a member with no samples enqueues nothing
+            if (rc != RT_OK) remember(rc, std::string("rt_render_device: ") + rt_last_error_detail(s.ctx));
+        }
+        if (rc != RT_OK)  // the low byte of the failure word becomes 1 (behind the zeroing, on the same stream)
+            (void)hipMemsetAsync((unsigned char*)(s.d_accum + elems), 1, 1, s.stream);
     }
-    // the one exchange of the frame: every member's buffer becomes the sum, on the stream its kernel ran on
-    G_NCCL(g, R->GroupStart());
-    ncclResult_t first_bad = ncclSuccess;
+    // ---- step 3: the one exchange of the frame -- every member's buffer becomes the sum, on the stream its kernel ran on
+    for (Member& m : g->members) {
+        if (!m.collective_pending) continue;
+        (void)hipSetDevice(m.device);
+        const hipError_t e = hipStreamWaitEvent(m.slots[(size_t)slot].stream, m.last_collective, 0);
+        if (e != hipSuccess) remember(RT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+    }
+    ncclResult_t first_bad = R->GroupStart();
     for (Member& m : g->members) {
         Slot& s = m.slots[(size_t)slot];
-        const ncclResult_t r = R->AllReduce(s.d_accum, s.d_accum, elems, ncclInt64, ncclSum, m.comm, s.stream);
+        const ncclResult_t r = R->AllReduce(s.d_accum, s.d_accum, elems + 1, ncclInt64, ncclSum, m.comm, s.stream);
         if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
     }
     const ncclResult_t end = R->GroupEnd();
-    if (first_bad != ncclSuccess) return gfail_nccl(g, first_bad, "ncclAllReduce");
-    G_NCCL(g, end);
+    if (first_bad == ncclSuccess) first_bad = end;
+    for (Member& m : g->members) {
+        Slot& s = m.slots[(size_t)slot];
+        (void)hipSetDevice(m.device);
+        hipError_t e = hipEventRecord(m.last_collective, s.stream);
+        m.collective_pending = e == hipSuccess;
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_failed, s.d_accum + elems, sizeof(int64_t), hipMemcpyDeviceToHost, s.stream);
+        if (e != hipSuccess) remember(RT_ERR_HIP, std::string("behind the all-reduce: ") + hipGetErrorString(e));
+    }
+    if (first_bad != ncclSuccess) return gfail_nccl(g, first_bad, "ncclAllReduce (the communicator is not usable any more)");
+    if (first_rc != RT_OK) return gfail(g, first_rc, first_detail + " (the collective was joined; the frame is incomplete on every rank)");
     for (Member& m : g->members) {
         m.slots[(size_t)slot].width = p->width;
         m.slots[(size_t)slot].height = p->height;
@@ -315,10 +409,18 @@ int rt_group_render_async(rt_group* g, const rt_camera_desc* cam, const rt_rende
 int rt_group_wait(rt_group* g, int slot) {
     if (!g) return RT_ERR_INVALID_ARGUMENT;
     if (!slot_ok(g, slot)) return gfail(g, RT_ERR_INVALID_ARGUMENT, "bad slot");
+    int64_t failed = 0;
     for (Member& m : g->members) {
+        Slot& s = m.slots[(size_t)slot];
         G_HIP(g, hipSetDevice(m.device));
-        G_HIP(g, hipStreamSynchronize(m.slots[(size_t)slot].stream));
+        G_HIP(g, hipStreamSynchronize(s.stream));
+        if (*s.h_failed != 0) {  // (of the last frame this slot was given; the member that failed reports it as well)
+            failed = *s.h_failed;
+            s.width = s.height = 0;  // the slot holds no frame
+        }
     }
+    if (failed != 0)
+        return gfail(g, RT_ERR_COMM, std::to_string(failed) + " member(s) of the group could not render their share: the summed frame is incomplete");
     return RT_OK;
 }
 

@@ -57,6 +57,8 @@ def load():
     L.rt_render_device.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
     L.rt_context_synchronize.restype = C.c_int
     L.rt_context_synchronize.argtypes = [ctx_p]
+    L.rt_render_check.restype = C.c_int
+    L.rt_render_check.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params)]
     L.rt_render_noalloc.restype = C.c_int
     L.rt_render_noalloc.argtypes = [ctx_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_void_p]
     L.rt_read_sums.restype = C.c_int
@@ -96,6 +98,10 @@ def load():
     L.rt_group_render_async.argtypes = [grp_p, C.POINTER(abi.rt_camera_desc), C.POINTER(abi.rt_render_params), C.c_int]
     L.rt_group_wait.restype = C.c_int
     L.rt_group_wait.argtypes = [grp_p, C.c_int]
+    L.rt_group_reserve.restype = C.c_int
+    L.rt_group_reserve.argtypes = [grp_p, C.c_int, C.c_int]
+    L.rt_group_set_fail_next.restype = C.c_int
+    L.rt_group_set_fail_next.argtypes = [grp_p, C.c_int]
     L.rt_group_read.restype = C.c_int
     L.rt_group_read.argtypes = [grp_p, C.c_int, C.c_void_p]
     L.rt_group_device_sums.restype = C.c_void_p
@@ -121,13 +127,13 @@ def load():
 
 EXPORTED_SYMBOLS = [
     "rt_get_device_count", "rt_context_create", "rt_context_destroy", "rt_scene_upload", "rt_render",
-    "rt_render_device", "rt_context_synchronize", "rt_context_set_exact_only", "rt_context_set_force_graph",
+    "rt_render_device", "rt_context_synchronize", "rt_render_check", "rt_context_set_exact_only", "rt_context_set_force_graph",
     "rt_context_take_stats", "rt_context_kernels_for",
     "rt_first_hit", "rt_camera_init", "rt_write_color", "rt_write_ppm", "rt_error_string", "rt_last_error_detail",
     "rt_render_noalloc", "rt_read_sums", "rt_split_samples", "rt_group_create", "rt_comm_id_create", "rt_group_create_rank", "rt_group_destroy",
     "rt_group_size", "rt_group_local_count", "rt_group_frame_slots", "rt_group_context", "rt_group_scene_upload",
     "rt_group_render", "rt_group_render_async", "rt_group_wait", "rt_group_read", "rt_group_device_sums",
-    "rt_group_take_stats", "rt_group_last_error_detail",
+    "rt_group_take_stats", "rt_group_last_error_detail", "rt_group_reserve", "rt_group_set_fail_next",
 ]
 
 
@@ -247,6 +253,10 @@ class Context:
     def synchronize(self):
         self._check(self._L.rt_context_synchronize(self._h), "rt_context_synchronize")
 
+    def render_check(self, cam, params) -> int:
+        """rt_render_check: the code rt_render_device would return for these arguments (0 = accepted); enqueues nothing."""
+        return int(self._L.rt_render_check(self._h, C.byref(cam), C.byref(params)))
+
     def read_sums(self, d_accum_ptr: int, width, height) -> np.ndarray:
         """rt_read_sums: device fixed-point sums -> host doubles [H,W,3] (waits for the context's stream)."""
         out = np.zeros((height, width, 3), dtype=np.float64)
@@ -361,6 +371,14 @@ class Group:
 
     def wait(self, slot=0):
         self._check(self._L.rt_group_wait(self._h, int(slot)), "rt_group_wait")
+
+    def reserve(self, width, height):
+        """rt_group_reserve: allocate every slot's buffers for frames of this size now."""
+        self._check(self._L.rt_group_reserve(self._h, int(width), int(height)), "rt_group_reserve")
+
+    def set_fail_next(self, local_index=0):
+        """Validation: the next render_async treats this local member's launch as failed."""
+        self._check(self._L.rt_group_set_fail_next(self._h, int(local_index)), "rt_group_set_fail_next")
 
     def read(self, width, height, slot=0) -> np.ndarray:
         out = np.zeros((height, width, 3), dtype=np.float64)

@@ -138,3 +138,117 @@ def test_read_sums_equals_rt_render(scene_c2, single):
         torch.cuda.synchronize()
         out = ctx.read_sums(big.data_ptr(), 2, 1)
         assert np.array_equal(out.ravel(), big.cpu().numpy().astype(np.float64) / 2.0 ** abi.RT_ACCUM_FRAC_BITS)
+
+
+def test_a_member_that_fails_still_joins_the_collective_and_every_wait_reports_it(scene_c2, single):
+    """A launch failure on one member after the checks have passed (requested through the validation switch): the call
+    returns the error, but only after the all-reduce has been joined -- no peer would be left waiting in it --, the
+    frame's failure word travels with the sums, and the group renders the next frame as if nothing had happened."""
+    cam = lib.camera(*CAM_C2)
+    with lib.Group(devices=[0], frame_slots=2) as g:
+        g.upload(scene_c2)
+        g.reserve(W, H)
+        g.set_fail_next(0)
+        with pytest.raises(lib.RtError) as e:
+            g.render_async(cam, abi.render_params(W, H, SPP, 50, seed=1), slot=0)
+        assert e.value.code == abi.RT_ERR_HIP and "collective was joined" in str(e.value)
+        with pytest.raises(lib.RtError) as e:       # nothing hangs, and the wait reports what every rank's wait reports
+            g.wait(0)
+        assert e.value.code == abi.RT_ERR_COMM and "1 member(s)" in str(e.value)
+        with pytest.raises(lib.RtError):
+            g.read(W, H, slot=0)                    # the slot holds no frame
+        # the failure word as a peer sees it: the word behind the slot's 3 W H sums, summed over the members
+        n = 3 * W * H
+        src, ctx = g.device_sums(0, 0), g.context(0, 0)
+        assert not ctx.read_sums(src, W, H).any()   # the failed member's share (here: everything) is missing
+        tail = ctx.read_sums(src + 8 * (n - 2), 1, 1).ravel() * 2.0 ** abi.RT_ACCUM_FRAC_BITS
+        assert tail.tolist() == [0.0, 0.0, 1.0]     # one member failed
+        # the communicator is still good: the next frames, on either slot, are whole
+        for k, slot in ((1, 0), (2, 1)):
+            g.render_async(cam, abi.render_params(W, H, SPP, 50, seed=k), slot=slot)
+        for k, slot in ((1, 0), (2, 1)):
+            g.wait(slot)
+            assert np.array_equal(g.read(W, H, slot=slot), single[k][0])
+
+
+def test_refusals_come_before_anything_is_enqueued(scene_c2, single):
+    """What can be refused is refused for every member before a kernel or a collective is enqueued: the slot keeps the
+    frame it held, and rt_render_check gives the same verdict without rendering."""
+    cam = lib.camera(*CAM_C2)
+    with lib.Group(devices=[0]) as g:
+        g.upload(scene_c2)
+        got, _ = g.render(cam, abi.render_params(W, H, SPP, 50, seed=4))
+        assert np.array_equal(got, single[4][0])
+        bad = abi.render_params(W, H, SPP, 50, seed=4, flags=abi.RT_RENDER_IMPORTANCE)  # a sphere list has no light shapes
+        ctx = g.context(0, 0)
+        assert ctx.render_check(cam, bad) == abi.RT_ERR_UNSUPPORTED_SCENE
+        assert ctx.render_check(cam, abi.render_params(W, H, SPP, 50, seed=4)) == abi.RT_OK
+        with pytest.raises(lib.RtError) as e:
+            g.render_async(cam, bad, slot=0)
+        assert e.value.code == abi.RT_ERR_UNSUPPORTED_SCENE
+        g.wait(0)
+        assert np.array_equal(g.read(W, H, slot=0), single[4][0])  # untouched
+
+
+needs_two_gpus = pytest.mark.skipif(lib.load().rt_get_device_count() < 2, reason="needs two GPUs")
+
+
+@needs_two_gpus
+def test_two_devices_in_one_process_equal_the_single_gpu_frame(scene_c2, single):
+    """The real thing: two members on two GPUs (ncclCommInitAll), samples split 5 + 4, one all-reduce per frame."""
+    cam = lib.camera(*CAM_C2)
+    with lib.Group(devices=[0, 1], frame_slots=3) as g:
+        assert (g.size, g.local_count) == (2, 2)
+        g.upload(scene_c2)
+        got, st = g.render(cam, abi.render_params(W, H, SPP, 50, seed=1))
+        assert np.array_equal(got, single[1][0])
+        assert st["samples"] == W * H * SPP and st["rays"] == single[1][1]["rays"] and st["kernel_launches"] == 2
+        for k in range(3):
+            g.render_async(cam, abi.render_params(W, H, SPP, 50, seed=1 + k), slot=k)
+        for k in range(3):
+            g.wait(k)
+            assert np.array_equal(g.read(W, H, slot=k), single[1 + k][0])
+        # a failure on the second member reaches the first member's copy of the frame through the all-reduce
+        g.set_fail_next(1)
+        with pytest.raises(lib.RtError):
+            g.render_async(cam, abi.render_params(W, H, SPP, 50, seed=1), slot=0)
+        with pytest.raises(lib.RtError) as e:
+            g.wait(0)
+        assert e.value.code == abi.RT_ERR_COMM
+        got, _ = g.render(cam, abi.render_params(W, H, SPP, 50, seed=5))
+        assert np.array_equal(got, single[5][0])
+
+
+def _rank_main(rank, world, cid, scene_path, out_q):
+    import numpy as np
+    from raytracing_amd import abi, lib
+    from tests.conftest import CAM_C2
+    cam = lib.camera(*CAM_C2)
+    with lib.Group(device=rank, rank=rank, world=world, comm_id=cid, frame_slots=2) as g:
+        g.upload(abi.load_scene(scene_path))
+        for k in range(2):
+            g.render_async(cam, abi.render_params(W, H, SPP, 50, seed=1 + k), slot=k)
+        frames = []
+        for k in range(2):
+            g.wait(k)
+            frames.append(g.read(W, H, slot=k))
+        out_q.put((rank, frames))
+
+
+@needs_two_gpus
+def test_two_ranks_in_two_processes_equal_the_single_gpu_frame(single):
+    """One process per GPU: the id from rank 0, ncclCommInitRank on both, two frames in flight."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    cid = lib.comm_id_create()
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, cid, gold("scene_c2.rtsc"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for k in range(2):
+            assert np.array_equal(results[rank][k], single[1 + k][0])
