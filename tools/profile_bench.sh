@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-pipelined $*"
 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
     python3 "$ROOT/bench.py" $ARGS > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || { echo "trace pass failed"; exit 1; }
@@ -17,7 +17,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OU
 pass() {  # name, counters...
     local name=$1; shift
     timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o bench -- \
-        python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/${name}_bench.json" 2> "$OUT/$name.err" \
+        python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-configs --no-pipelined > "$OUT/${name}_bench.json" 2> "$OUT/$name.err" \
         || { echo "counter pass $name failed"; tail -5 "$OUT/$name.err"; exit 1; }
 }
 pass pmcA SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE GRBM_COUNT

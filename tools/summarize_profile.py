@@ -36,6 +36,11 @@ def main():
     elif os.path.exists(os.path.join(src, "trace_bench.txt")):
         with open(os.path.join(src, "trace_bench.txt")) as fp:
             bench_text = "".join(l for l in fp if "amdgpu.ids" not in l).strip()
+    config_line = None  # tools/bench_config.py prints one JSON line
+    try:
+        config_line = json.loads(bench_text.splitlines()[-1]) if bench_text else None
+    except ValueError:
+        config_line = None
 
     counters = collections.OrderedDict()
     launches = {}
@@ -86,9 +91,17 @@ def main():
         derived["l1_requests_served_without_l2"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
 
     if bench is not None:
-        command = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+        command = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-pipelined"
         title = "bench.py, One-Weekend final scene"
         script = "tools/profile_bench.sh"
+    elif config_line is not None:
+        command = f"python3 tools/bench_config.py {config_line['config_name']} {config_line['spp']}"
+        title = f"{config_line['workload']}, {config_line['width']}x{config_line['height']}x{config_line['spp']}"
+        script = "tools/profile_config.sh"
+        if "executed_vector_flop_per_launch" in derived:
+            derived["executed_flop_per_ray"] = derived["executed_vector_flop_per_launch"] / config_line["rays"]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            derived["hbm_GBs_under_profiler"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / (avg_ms * 1e-3) / 1e9
     else:
         command = "python3 tools/bench_scenes.py <spp> <scene>"
         title = f"tools/bench_scenes.py ({out_name})"
@@ -96,7 +109,7 @@ def main():
     sys.path.insert(0, ROOT)
     from bench import kernel_source_sha256  # the tree the library under the profiler was built from
     summary = {"tag": tag, "command": command + " (under rocprofv3)", "kernel_source_sha256": kernel_source_sha256(),
-               "kernel_stats": stats_rows, "bench_line_under_profiler": bench if bench is not None else bench_text,
+               "kernel_stats": stats_rows, "bench_line_under_profiler": bench if bench is not None else (config_line if config_line is not None else bench_text),
                "counters_per_launch": counters, "derived": derived}
     with open(os.path.join(out_dir, f"{tag}_{out_name}.json"), "w") as fp:
         json.dump(summary, fp, indent=1)
