@@ -960,7 +960,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     // LDS per wave: the traversal stack; without it the candidate lists of the leaf sets; without those nothing (a
     // variant that needs neither is not held back by LDS: 4 workgroups of 40 KB would not fit a CU's 160 KB)
     constexpr int STACK_WORDS = (F & F_STACK) != 0 ? STACK_CAP * 64 : ((F & F_SET) != 0 ? CAND_CAP * 32 + ROW_WORDS * 64 : 64);
-    __shared__ uint32_t s_stack[4][STACK_WORDS];
+    static_assert((STACK_WORDS * 4) % 8 == 0, "a wave's slice of the stack holds whole 8-byte words (64-bit LDS operations of spread_exact_tests)");
+    __shared__ __align__(16) uint32_t s_stack[4][STACK_WORDS];
 #if RT_PARK_PATH_STATE
     constexpr bool PARK = MIN_WAVES >= 3 && (F & F_SET) != 0 && (F & F_STACK) == 0;  // the variant that spills most and has the LDS to spare
     __shared__ double s_park[4][PARK ? 6 : 1][64];
@@ -1152,7 +1153,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
 
 // ---------------------------------------------------------------- first-hit kernel
 __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs A) {
-    __shared__ uint32_t s_stack[4][STACK_CAP * 64];
+    __shared__ __align__(16) uint32_t s_stack[4][STACK_CAP * 64];
     const int lane = threadIdx.x & 63;
     uint32_t* stack = s_stack[threadIdx.x >> 6];
     const uint32_t npix = (uint32_t)A.width * (uint32_t)A.height;

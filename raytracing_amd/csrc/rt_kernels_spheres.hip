@@ -71,8 +71,9 @@ template <bool TIMED>
 __global__ void __launch_bounds__(RT_SPHERES_WG, TIMED ? RT_MIN_WAVES_TIMED : RT_MIN_WAVES_PER_SIMD) k_render_spheres(const RenderArgs A_in) {
     constexpr int WG_WAVES = RT_SPHERES_WG / 64;
     const RenderArgs& A = A_in;
-    __shared__ uint16_t s_list[WG_WAVES][CAND_CAP * 64];
-    __shared__ uint32_t s_rows[WG_WAVES][ROW_WORDS * 64];
+    // (16-byte aligned, slices of whole 8-byte words: spread_exact_tests runs 64-bit LDS operations on them)
+    __shared__ __align__(16) uint16_t s_list[WG_WAVES][CAND_CAP * 64];
+    __shared__ __align__(16) uint32_t s_rows[WG_WAVES][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
     uint32_t* rows = s_rows[threadIdx.x >> 6];
@@ -321,8 +322,8 @@ __global__ void __launch_bounds__(RT_SPHERES_WG, TIMED ? RT_MIN_WAVES_TIMED : RT
 // One lane per pixel centre; definition in raytracing_amd.h (rt_first_hit).
 template <bool TIMED>
 __global__ void __launch_bounds__(256) k_first_hit_spheres(const FirstHitArgs A) {
-    __shared__ uint16_t s_list[4][CAND_CAP * 64];
-    __shared__ uint32_t s_rows[4][ROW_WORDS * 64];
+    __shared__ __align__(16) uint16_t s_list[4][CAND_CAP * 64];
+    __shared__ __align__(16) uint32_t s_rows[4][ROW_WORDS * 64];
     const int lane = threadIdx.x & 63;
     uint16_t* list = s_list[threadIdx.x >> 6];
     uint32_t* rows = s_rows[threadIdx.x >> 6];

@@ -352,6 +352,10 @@ __device__ __forceinline__ void exact_one(const SphereSetDev& S, int j, d3 o, d3
 #endif
 constexpr int SPREAD_CAP = RT_SPREAD_CAP;
 static_assert(4 * SPREAD_CAP <= ITEM_CAP / 2, "pairs and results of the spread tests use the queue's words");
+// spread_exact_tests reads and writes `rows + SPREAD_CAP` and `list` as 64-bit words (ds_min_u64): the callers declare
+// both arrays 16-byte aligned, and every wave's slice and the offset inside it must be whole 8-byte words
+static_assert((SPREAD_CAP * 4) % 8 == 0 && (ROW_WORDS * 64 * 4) % 8 == 0 && (CAND_CAP * 64 * 2) % 8 == 0,
+              "64-bit LDS operations need 8-byte aligned slices");
 static_assert(64 * 3 <= CAND_CAP * 32, "per-ray slots of the spread tests use the candidate lists' words");
 
 #ifndef RT_SPREAD_EXACT_TESTS

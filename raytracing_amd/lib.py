@@ -241,12 +241,15 @@ class Context:
         return out, stats_dict(st)
 
     def render_device(self, cam, params, d_accum_ptr: int):
-        """Enqueue a render that ADDS fixed-point sums into device memory at `d_accum_ptr`."""
+        """Enqueue a render that ADDS fixed-point sums into device memory at `d_accum_ptr`.  One writer at a time: calls
+        that add to the same buffer must be ordered (one stream, or synchronised) -- from about fifty samples per pixel
+        on, a pixel's sums reach memory by a plain load, add and store, not by atomics."""
         self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_accum_ptr)),
                     "rt_render_device")
 
     def render_noalloc(self, cam, params, d_out_ptr: int):
-        """rt_render_noalloc: enqueue a render that leaves DOUBLE sums in device memory at `d_out_ptr`."""
+        """rt_render_noalloc: enqueue a render that leaves DOUBLE sums in device memory at `d_out_ptr`.  All contexts of
+        one GPU share that GPU's scratch frame: calls that overlap in time on one GPU (different streams) race."""
         self._check(self._L.rt_render_noalloc(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_out_ptr)),
                     "rt_render_noalloc")
 

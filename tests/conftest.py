@@ -5,9 +5,12 @@ import sys
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  -- first, before anything loads libraytracing_amd.so: PyTorch ships its own HIP runtime
-#                              (same soname as the system's), and a process must settle on one copy before either
-#                              library touches the GPU; some tests hand torch tensors to the library
+try:  # first, before anything loads libraytracing_amd.so: PyTorch ships its own HIP runtime (same soname as the
+    # system's), and a process must settle on one copy before either library touches the GPU; some tests hand torch
+    # tensors to the library.  Without PyTorch the CPU tests still run (raytracing_amd.lib guards the import likewise).
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -91,6 +94,20 @@ def make_sphere_scene(spheres, materials, sky_mode=abi.RT_SKY_GRADIENT, backgrou
 # at most LIBM_MAX_VALUES values per render off by at most LIBM_MAX_UNITS units of 2^-36 (ray counts are asserted
 # exactly where the test has them).  Every other world -- configurations 1 to 3 among them -- is held to exact equality.
 LIBM_MAX_UNITS, LIBM_MAX_VALUES = 2, 4
+
+
+def scene_calls_libm(scene, flags=0):
+    """Whether rendering this world evaluates log / sin / cos / acos / atan2 on the device: a constant medium draws its
+    free-flight distance with log (B2/constant_medium.h:50), an isotropic material comes with one, a noise texture
+    takes a sin (B2/texture.h:56), an image texture reads the sphere's uv, which are an acos and an atan2
+    (B2/sphere.h:25-38), and book 3's light and cosine sampling (RT_RENDER_IMPORTANCE) calls sin and cos.  Nothing else
+    does: a checker texture needs only the sign of its sines, rotate_y's sine and cosine are worked out on the host."""
+    if flags & abi.RT_RENDER_IMPORTANCE:
+        return True
+    if np.any(scene.nodes["kind"] == abi.RT_NODE_MEDIUM) or np.any(scene.materials["kind"] == abi.RT_MAT_ISOTROPIC):
+        return True
+    kinds = scene.textures["kind"] if len(scene.textures) else np.zeros(0, dtype=np.int32)
+    return bool(np.any((kinds == abi.RT_TEX_NOISE) | (kinds == abi.RT_TEX_IMAGE)))
 
 
 def assert_sums_match(got, want, libm_world, what=None):

@@ -8,7 +8,7 @@ import pytest
 
 from raytracing_amd import abi, lib
 from tests import oracle_binding as ob
-from tests.conftest import assert_sums_match, gold
+from tests.conftest import assert_sums_match, gold, scene_calls_libm
 
 pytestmark = pytest.mark.gpu
 FRAC = 2.0 ** abi.RT_ACCUM_FRAC_BITS
@@ -199,7 +199,7 @@ def test_random_world_matches_oracle(seed, monkeypatch):
             c.close()
         assert np.array_equal(got, exact), (seed, set_min)
         assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, set_min)
-        assert_sums_match(got, want, True, (seed, set_min))
+        assert_sums_match(got, want, scene_calls_libm(scene), (seed, set_min))
         assert np.array_equal(ids, want_ids), (seed, set_min)
 
 
@@ -221,7 +221,7 @@ def test_rays_that_overflow_walk_a_mixed_subtree_as_the_reference_does(monkeypat
             c.upload(scene)
             got, st = c.render(cam, p)
         assert st["rays"] == ost["rays"], set_min
-        assert_sums_match(got, want, True, set_min)
+        assert_sums_match(got, want, scene_calls_libm(scene), set_min)
 
 
 def random_sphere_world(seed):
@@ -353,7 +353,7 @@ def test_random_world_importance_sampling_matches_oracle(seed, monkeypatch):
             finally:
                 c.close()
             assert st["rays"] == ost["rays"] and st["nan_samples"] == ost["nan_samples"], (seed, flags, set_min)
-            assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, flags, set_min))
+            assert_sums_match(got, fixed.astype(np.float64) / FRAC, scene_calls_libm(scene, flags), (seed, flags, set_min))
 
 
 def random_big_set_world(seed):
@@ -414,7 +414,7 @@ def test_random_big_set_world_matches_oracle(seed, monkeypatch):
         finally:
             c.close()
         assert st["rays"] == ost["rays"], (seed, set_min)
-        assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, set_min))
+        assert_sums_match(got, fixed.astype(np.float64) / FRAC, scene_calls_libm(scene), (seed, set_min))
         assert np.array_equal(got, exact) and np.array_equal(ids, want_ids), (seed, set_min)
 
 
@@ -530,7 +530,7 @@ def test_random_world_at_other_scales(family, seed, scale, monkeypatch):
         finally:
             c.close()
         assert st["rays"] == ost["rays"], (seed, scale, set_min)
-        assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, (seed, scale, set_min))
+        assert_sums_match(got, fixed.astype(np.float64) / FRAC, scene_calls_libm(scene), (seed, scale, set_min))
         assert np.array_equal(ids, ob.first_hit(scene, ocam, 60, 45)), (seed, scale, set_min)
 
 
@@ -568,4 +568,4 @@ def test_perlin_noise_beyond_the_int_range(scale):
     finally:
         c.close()
     assert st["rays"] == ost["rays"]
-    assert_sums_match(got, fixed.astype(np.float64) / FRAC, True, None)
+    assert_sums_match(got, fixed.astype(np.float64) / FRAC, scene_calls_libm(scene), None)

@@ -14,7 +14,7 @@ import pytest
 
 from raytracing_amd import abi, lib
 from tests import oracle_binding as ob
-from tests.conftest import CAM_C2, assert_sums_match, gold
+from tests.conftest import CAM_C2, assert_sums_match, gold, scene_calls_libm
 from tests.test_oracle_golden_b2 import B2_SCENES, camera_b2, load_b2
 
 pytestmark = pytest.mark.gpu
@@ -43,10 +43,11 @@ def oracle_sums(scene, cam, p):
 LIBM_WORLDS = {"two_perlin", "earth", "earth_real", "simple_light", "cornell_smoke", "final"}
 
 
-@pytest.mark.parametrize("name", B2_SCENES)
+@pytest.mark.parametrize("name", B2_SCENES, ids=lambda n: f"{n}-{'libm_tolerance' if n in LIBM_WORLDS else 'exact'}")
 def test_scene_render_matches_oracle(ctx, kat_b2, name):
     k = kat_b2[name]
     scene = load_b2(name)
+    assert scene_calls_libm(scene) == (name in LIBM_WORLDS)  # the test id says which bar the world is held to
     cam = camera_b2(k, lib.camera)
     ctx.upload(scene)
     for W, H, spp, seed, begin in ((72, 54, 5, 3, 0), (33, 21, 3, 2 ** 33 + 1, 7)):

@@ -26,6 +26,15 @@ def test_noalloc_render_equals_rt_render_on_two_calls_in_a_row(scene_c2):
         for (W, H, spp, seed), g in zip(calls, got):
             want, _ = ctx.render(cam, abi.render_params(W, H, spp, 50, seed=seed))
             assert np.array_equal(g, want)
+        # the property the entry point exists for: after a first call, a call leaves the device's free memory as it
+        # found it (no hipMalloc, no event, no staging buffer), and can be repeated any number of times
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info(0)
+        for W, H, spp, seed in calls * 3:
+            ctx.render_noalloc(cam, abi.render_params(W, H, spp, 50, seed=seed), out.data_ptr())
+        ctx.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(0)
+        assert free_after == free_before, (free_before, free_after)
         # nothing to render: the output is overwritten with zeros
         ctx.render_noalloc(cam, abi.render_params(40, 30, 0, 50), out.data_ptr())
         ctx.synchronize()

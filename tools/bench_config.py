@@ -13,7 +13,7 @@ from raytracing_amd import abi, lib  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c4"
 cfg = CONFIGS[name]
-spp = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["spp"]
+spp = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else cfg["spp"]
 launches = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 W, H = cfg["width"], cfg["height"]
 flags = abi.RT_RENDER_IMPORTANCE if cfg["flags"] == "importance" else 0

@@ -5,7 +5,7 @@
 # One rocprofv3 run per pass; a counter pass never shares a run with a trace domain other than the kernel trace, and
 # stays inside the per-block counter limits (8 SQ, 4 TCC with FETCH_SIZE = 3 and WRITE_SIZE = 2, 4 TCP, 2 GRBM).
 set -u
-TAG=${1:?tag}; NAME=${2:?config}; SPP=${3:-}
+TAG=${1:?tag}; NAME=${2:?config}; SPP=${3:--}   # "-": the configuration's own sample count
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
