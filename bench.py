@@ -21,8 +21,9 @@ Prints ONE JSON line on rank 0.  What is timed, at every N alike:
                          frame behind it -- per frame the time from first launch to summed buffer complete on every
                          GPU.  This is `value`, at N = 1 and at N > 1, so scaling compares like with like.
   pipelined              the same K frames with three frames in flight (own streams and buffers): the end of one
-                         frame's launch and its all-reduce overlap the next frame's kernel.  Measured on one GPU by
-                         default, on several only with --pipelined.
+                         frame's launch and its all-reduce overlap the next frame's kernel.  Measured after the
+                         headline, at every GPU count (--no-pipelined skips it); on several GPUs a watchdog prints the
+                         line without it should that phase stall.
 Beside them, on one GPU: the correctness gate of the headline run itself (the last timed frame against the image of
 the reference program: RMSE, PSNR, image mean), the other BASELINE configurations (`configs`), each with its kernel's
 roofline from the committed counter profile of that configuration, and the reference's own CPU renderer timed on the
@@ -352,11 +353,10 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frames in flight of the headline measurement (`value`).  Default 1 at every GPU count: a frame "
                          "is timed from its first launch to its summed buffer, the next one starts behind it")
-    ap.add_argument("--pipelined", action="store_true",
-                    help=f"also measure the throughput with {PIPELINE_SLOTS} frames in flight (always done on one GPU; on "
-                         "several GPUs only with this flag: successive all-reduces of one communicator then run on "
-                         "different streams, ordered by the library's event chain)")
-    ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help=f"skip the second measurement, the throughput with {PIPELINE_SLOTS} frames in flight (on several GPUs "
+                         "successive all-reduces of one communicator then run on different streams, ordered by the "
+                         "library's event chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (`configs` block)")
     args = ap.parse_args()
@@ -400,7 +400,7 @@ def main():
     cam = cfg2["camera"](lib)
     W, H, spp = args.width, args.height, args.spp
     in_flight = max(1, args.frames_in_flight)
-    do_pipelined = not args.no_pipelined and (one_gpu or args.pipelined) and in_flight < PIPELINE_SLOTS
+    do_pipelined = not args.no_pipelined and in_flight < PIPELINE_SLOTS
     n_slots = max(in_flight, PIPELINE_SLOTS if do_pipelined else 1)
 
     verbose = os.environ.get("RT_BENCH_VERBOSE") == "1"
@@ -468,25 +468,10 @@ def main():
         run.use = in_flight
         gate = gate_against_reference(lib, "c2", cfg2, run.read_frame(last_frame), spp) if args.depth == 50 else None
 
-    # ---- the same frames with three in flight
-    pipelined = None
-    if do_pipelined:
-        dp, _, (psamples, _, _) = timed(args.warmup + args.steps, PIPELINE_SLOTS)
-        pipelined = {"frames_in_flight": PIPELINE_SLOTS, "ms_per_frame": dp / args.steps * 1e3, "msamples_per_s": psamples / dp / 1e6,
-                     "frames": args.steps, "note": "the end of a frame's launch and its all-reduce overlap the next frame's kernel"}
-        say("pipelined region done")
-    run.close()
-
-    # ---- the other BASELINE configurations, one frame each at their own size (one GPU only)
-    configs = None
-    if one_gpu and rank == 0 and not args.no_configs:
-        configs = {}
-        with lib.Context(0) as ctx:
-            for name in ("c1", "c3", "c4", "c5"):
-                configs[name] = render_config(lib, abi, ctx, name, CONFIGS[name])
-                say(f"{name} done")
-
-    if rank == 0:
+    # What rank 0 prints; called once -- at the end, or by the watchdog of the pipelined phase.
+    def report(pipelined, configs):
+        if rank != 0:
+            return
         assert samples == W * H * spp * args.steps, (samples, W * H * spp * args.steps)
         value = samples / dt / 1e6
         # roofline of the dominant kernel (k_render_spheres) on THIS process's GPUs: executed flops of its launches
@@ -528,8 +513,7 @@ def main():
             "value_is": ("single_frame: K frames one after the other, one in flight -- the same at every GPU count"
                          if in_flight == 1 else f"throughput with {in_flight} frames in flight"),
             "single_frame": single,
-            "pipelined": pipelined if pipelined is not None else
-                         ("not measured: on several GPUs only with --pipelined" if not one_gpu and not args.pipelined else None),
+            "pipelined": pipelined,
             "mrays_per_s": rays / dt / 1e6, "rays_per_sample": rays / max(1, samples), "nan_samples": bad,
             "rmse_gate": gate,
             "roofline": roof,
@@ -541,6 +525,45 @@ def main():
         if configs is not None:
             out["configs"] = configs
         print(json.dumps(out), flush=True)
+
+    # ---- the same frames with three in flight.  On several GPUs this is the first time successive all-reduces of one
+    # communicator run on different streams beside persistent kernels that fill every CU: should the phase stall, every
+    # rank's watchdog ends its process, rank 0's after printing the line with the headline alone.
+    pipelined = None
+    if rank == 0:
+        print(f"bench.py: headline measured: {samples / dt / 1e6:.1f} Msamples/s, {dt / args.steps * 1e3:.3f} ms per frame on {n_gpus} GPU(s), "
+              f"one frame in flight" if in_flight == 1 else f"bench.py: headline measured with {in_flight} frames in flight", file=sys.stderr, flush=True)
+    if do_pipelined:
+        import threading
+        limit = float(os.environ.get("RT_BENCH_PIPELINED_TIMEOUT_S", "120"))
+
+        def give_up():
+            report({"frames_in_flight": PIPELINE_SLOTS, "ms_per_frame": None, "msamples_per_s": None,
+                    "note": f"not measured: the phase did not finish within {limit:.0f} s"}, None)
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, give_up) if not one_gpu else None
+        if watchdog:
+            watchdog.daemon = True
+            watchdog.start()
+        dp, _, (psamples, _, _) = timed(args.warmup + args.steps, PIPELINE_SLOTS)
+        if watchdog:
+            watchdog.cancel()
+        pipelined = {"frames_in_flight": PIPELINE_SLOTS, "ms_per_frame": dp / args.steps * 1e3, "msamples_per_s": psamples / dp / 1e6,
+                     "frames": args.steps, "note": "the end of a frame's launch and its all-reduce overlap the next frame's kernel"}
+        say("pipelined region done")
+    run.close()
+
+    # ---- the other BASELINE configurations, one frame each at their own size (one GPU only)
+    configs = None
+    if one_gpu and rank == 0 and not args.no_configs:
+        configs = {}
+        with lib.Context(0) as ctx:
+            for name in ("c1", "c3", "c4", "c5"):
+                configs[name] = render_config(lib, abi, ctx, name, CONFIGS[name])
+                say(f"{name} done")
+
+    report(pipelined, configs)
 
     if ranks:
         dist.destroy_process_group()
