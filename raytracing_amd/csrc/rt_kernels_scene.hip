@@ -1215,7 +1215,13 @@ static const SceneVariant g_variants[] = {
     {V_B, k_render_scene<V_B, RT_SCENE_WAVES_B>},
     {V_C & ~F_STACK, k_render_scene<V_C & ~F_STACK, RT_SCENE_WAVES_C_FLAT>},
     {V_C, k_render_scene<V_C, 2>},
-    {F_ALL | F_SET, k_render_scene<F_ALL | F_SET, RT_SCENE_WAVES_FLAT>},  // no object needs the stack (the Next-Week final scene)
+#ifndef RT_SCENE_NO_CHECKER_VARIANT
+#define RT_SCENE_NO_CHECKER_VARIANT 1
+#endif
+#if RT_SCENE_NO_CHECKER_VARIANT
+    {(F_ALL & ~F_CHECKER) | F_SET, k_render_scene<(F_ALL & ~F_CHECKER) | F_SET, RT_SCENE_WAVES_FLAT>},  // ... and no checker texture: the Next-Week final scene
+#endif
+    {F_ALL | F_SET, k_render_scene<F_ALL | F_SET, RT_SCENE_WAVES_FLAT>},  // no object needs the stack
     {F_ALL | F_STACK, k_render_scene<F_ALL | F_STACK, RT_SCENE_MIN_WAVES>},
     {F_ALL | F_SET | F_STACK, k_render_scene<F_ALL | F_SET | F_STACK, RT_SCENE_WAVES_SET>},
     {F_EVERY, k_render_scene<F_EVERY, RT_SCENE_MIN_WAVES>},
