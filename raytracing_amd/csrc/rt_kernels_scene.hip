@@ -509,6 +509,9 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 winner = sh.aux;
                                 sphere_j = sh.id;
                             }
+#ifdef RT_SCENE_PROBE
+                            if (overflowed) atomicAdd(&g_probe_total[15], 1ull);  // rays with more candidates than slots
+#endif
                             PROBE_MARK(PS_SET_SPHERES);
                         }
                         if constexpr ((F & F_RECT) != 0) {
@@ -1257,6 +1260,7 @@ void scene_probe_dump() {
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_total), sizeof(h)) != hipSuccess) return;
     static const char* names[] = {"other", "sphere", "moving", "xy", "xz", "yz", "box", "list", "bvh", "translate", "rotate", "medium"};
     if (h[14] == 0) return;  // nothing rendered since the last dump
+    std::fprintf(stderr, "scene probe: sphere-set rays with more candidates than slots: %llu\n", h[15]);
     std::fprintf(stderr, "scene probe: wave-traces %llu; stack loop: trips %llu (%.1f per trace), lane fill %.3f\n", h[14], h[12],
                  (double)h[12] / (double)h[14], h[12] ? (double)h[13] / (64.0 * (double)h[12]) : 0.0);
     for (int k = 0; k < 12; ++k)
