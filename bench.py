@@ -89,7 +89,7 @@ def kernel_source_sha256():
     """Hash of the kernel sources the library is built from: a committed counter summary carries the hash of the tree
     it was measured on, so figures taken from it can be marked stale once the kernels have changed."""
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.h*"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.inc"))):
         with open(path, "rb") as fp:
             h.update(os.path.basename(path).encode() + b"\0" + fp.read())
     return h.hexdigest()
