@@ -238,7 +238,7 @@ int rt_render(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params
  * (e.g. a torch int64 tensor), which the call ADDS to: zero it before the first call of a
  * frame.  The kernel is enqueued on the context's stream and the call returns without
  * waiting; rt_context_synchronize() waits.  Calls that add to the same buffer must be
- * ordered (one stream, or synchronised): from about fifty samples per pixel on a pixel's
+ * ordered (one stream, or synchronised): from 32 samples per pixel on a pixel's
  * sums reach memory by plain loads and stores, not atomics.  This is the entry point a multi-GPU caller
  * uses before summing the buffers of all ranks with an all-reduce.                      */
 int rt_render_device(rt_context* ctx, const rt_camera_desc* cam, const rt_render_params* params,

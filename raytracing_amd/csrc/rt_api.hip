@@ -37,8 +37,8 @@ struct rt_context {
     int blocks_per_cu_scene = 0;
     bool graph_can_importance = false;  // the uploaded world has light shapes and no isotropic material
     // sphere-list launches with at least this many samples per pixel use the pixel-by-pixel pass (measured
-    // crossover on config 2: slower by 0.5 ms at 32 spp, faster by 1.8 ms at 500 spp)
-    int pixel_pass_min_samples = 48;
+    // crossover on config 2 with 16 equal runs per pixel: 3 % slower at 24 spp, 3 % faster at 32)
+    int pixel_pass_min_samples = 32;
     int blocks_override = 0;
     std::string detail;
     bool exact_only = false;     // validation: bypass the float screen
@@ -78,6 +78,7 @@ struct rt_context {
 };
 
 static constexpr size_t MAX_TIMED_LAUNCHES = 256;
+
 
 // Scratch of rt_render_noalloc: device memory the kernels need beyond the caller's buffers, held in the code object
 // instead of coming from hipMalloc.  [0, 4) work-queue head, [64, 96) the four statistics counters,
@@ -1292,28 +1293,29 @@ static int check_render_args(rt_context* ctx, const rt_camera_desc* cam, const r
     return RT_OK;
 }
 
-// Longest run of samples of one pixel handed to a lane as one work item (RT_ITEM_SAMPLES overrides).  Eight by default.
-// The pixel-by-pixel plan gives a wave whole pixels, floor(64 / runs per pixel) of them at a time, so the runs per pixel
-// (= floor(samples / cap)) decide how many of its 64 lanes a batch fills: a cap between 8 and 32 that makes them 64, 32,
-// 16, 8 or 4 fills them all, and longer runs mean fewer items to fetch and finish (500 samples: 31 -> 16 runs, 68.1
-// against 69.1 ms with runs of 8; 250 samples: 15 -> 16 runs, 34.3 against 34.5 ms; bouncing spheres at 1000 samples:
-// 31 -> 32 runs, 149.2 against 151.1 ms).  Sums do not depend on the partition (fixed point).
+// What make_item_plan is given for a call: the longest run of samples of one pixel that forms a work item of the
+// frame-by-frame plan (eight; RT_ITEM_SAMPLES overrides), or, for the pixel-by-pixel plan, the number of runs a pixel's
+// samples are cut into (RT_ITEM_LEVELS overrides).  Sixteen: a power of two, so that four whole pixels fill a wave's 64
+// lanes, and the best or within 0.2 % of the best at every count measured on config 2 (62 samples per pixel: 9.20 ms
+// against 9.64 with six runs of 8 and one of 14; 63: 9.31 against 9.66; 125: 17.7 against 18.0; 250: 34.4 against 34.9;
+// 500: 67.8 against 68.0; 1000, 2000 and the bouncing spheres: level with 32 and 64; 4 runs: +8 %, 64 runs: +0.5 % at
+// 500 samples and +25 % at 63).  Sums do not depend on the partition (fixed point).
 static int item_cap_for(const rt_render_params* p, bool pixel_pass) {
-    int cap = 8;
-    if (pixel_pass && p->sample_count >= 200) {  // (below that, longer runs lengthen the launch's tail by what they save)
-        for (int runs = 64; runs >= 4; runs /= 2) {
-            const int c = p->sample_count / runs;
-            if (c >= 8 && c <= 32 && p->sample_count / c == runs) {
-                cap = c;
-                break;
-            }
+    (void)p;
+    if (!pixel_pass) {
+        int cap = 8;
+        if (const char* s = std::getenv("RT_ITEM_SAMPLES")) {
+            int v = std::atoi(s);
+            if (v >= 1) cap = v;
         }
+        return cap;
     }
-    if (const char* s = std::getenv("RT_ITEM_SAMPLES")) {
+    int runs = 16;
+    if (const char* s = std::getenv("RT_ITEM_LEVELS")) {
         int v = std::atoi(s);
-        if (v >= 1) cap = v;
+        if (v >= 1 && v <= 64) runs = v;
     }
-    return cap;
+    return runs;
 }
 
 // Enqueues the render kernel for a checked call on the context's stream: the samples are ADDED to d_accum_fixed; the
@@ -1324,8 +1326,8 @@ static int enqueue_render(rt_context* ctx, const rt_camera_desc* cam, const rt_r
 
     const uint32_t npix = (uint32_t)p->width * (uint32_t)p->height;
     const bool spheres = use_sphere_kernels(ctx, cam->time0, cam->time1);
-    // the pixel-by-pixel pass pays off from about fifty samples per pixel (63: 9.06 against 9.39 ms with three frames in
-    // flight, 9.85 against 9.86 alone; 32: 4.66 against 4.90 and 5.48 against 5.33; RT_PIXEL_PASS=0/1 overrides)
+    // the pixel-by-pixel pass pays off from 32 samples per pixel (config 2, kernel alone: 24 samples 4.20 against 4.06 ms,
+    // 32: 5.16 against 5.32, 48: 7.27 against 7.60, 63: 9.31 against 9.70; RT_PIXEL_PASS=0/1 overrides)
     bool pixel_pass = spheres && p->sample_count >= ctx->pixel_pass_min_samples;
     const int item_cap = item_cap_for(p, pixel_pass);
     const ItemPlan plan = make_item_plan(p->sample_count, item_cap, npix, pixel_pass);

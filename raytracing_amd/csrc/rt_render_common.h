@@ -381,26 +381,35 @@ __device__ __forceinline__ void add_i64_own(int64_t* p, int64_t v) { *p += v; }
 // the whole frame (one-sample runs last), so that the queue ends in fine grains spread over all pixels, whatever single
 // pixels cost.  Every item adds its sums to memory itself (three 64-bit atomics).
 //
-// Pixel-by-pixel plan (pixel_pass = true): K runs of `cap` samples and one run of the remaining R, numbered pixel by
-// pixel (all runs of pixel 0, then of pixel 1, ...).  A wave takes whole pixels from the queue (batches are multiples
-// of the runs per pixel while they fit 64 lanes), its lanes trace similar rays, and the sums of a pixel's runs meet in
-// the wave's accumulation cache (below) and reach memory once per pixel instead of once per run.  (Ending this queue in
+// Pixel-by-pixel plan (pixel_pass = true; `cap` then carries the NUMBER of runs per pixel, L): the N samples of a pixel in
+// L runs as equal as they can be -- the first N mod L runs hold floor(N / L) + 1 samples, the others floor(N / L) --
+// numbered pixel by pixel (all runs of pixel 0, then of pixel 1, ...).  A wave takes whole pixels from the queue (batches
+// are multiples of the runs per pixel while they fit 64 lanes; with L a power of two a batch fills all 64), its lanes trace
+// similar rays, and the sums of a pixel's runs meet in the wave's accumulation cache (below) and reach memory once per
+// pixel instead of once per run.  Equal runs matter: with K runs of 8 and one of the remaining 8..15 samples, the long run
+// was the last to finish of every pixel (63 samples per pixel: 9.66 -> 9.40 ms with runs of 7 and 8).  (Ending this queue in
 // fine grains as well -- one-sample items, or halved runs of every n-th pixel, after the long runs -- was measured and
 // changes nothing: the waves balance their own ends, see refill_work.)
+// In that plan ItemPlan::K = number of long runs, cap = their length, R = the length of the others.
 // (struct ItemPlan: rt_internal.h, beside the kernel arguments that carry it)
 __host__ __device__ inline ItemPlan make_item_plan(int32_t n_samples, int32_t cap, uint32_t npix, bool pixel_pass) {
     ItemPlan p;
-    p.cap = cap < 1 ? 1 : cap;
-    p.K = n_samples / p.cap - 1;
-    if (p.K < 0) p.K = 0;
-    p.R = n_samples - p.K * p.cap;
     p.npix = npix;
     if (pixel_pass) {
-        p.levels = p.K + (p.R > 0 ? 1 : 0);
+        int32_t runs = cap < 1 ? 1 : cap;
+        if (runs > n_samples) runs = n_samples > 0 ? n_samples : 1;
+        p.levels = n_samples > 0 ? runs : 0;
+        p.R = n_samples / runs;
+        p.K = n_samples - p.R * runs;  // runs that hold one sample more
+        p.cap = p.R + 1;
         p.bulk_items = npix * (uint32_t)p.levels;
         p.exclusive = (p.levels >= 1 && p.levels <= 64) ? 1 : 0;
         p.batch = p.exclusive != 0 ? (uint32_t)((64 / p.levels) * p.levels) : 64u;
     } else {
+        p.cap = cap < 1 ? 1 : cap;
+        p.K = n_samples / p.cap - 1;
+        if (p.K < 0) p.K = 0;
+        p.R = n_samples - p.K * p.cap;
         int bits = 0;
         for (int32_t r = p.R; r > 0; r >>= 1) ++bits;
         p.levels = p.K + bits;
@@ -424,7 +433,7 @@ __device__ __forceinline__ void item_lookup(const ItemPlan& p, uint32_t item, ui
         pixel = item / (uint32_t)p.levels;
 #endif
         const int level = (int)(item - pixel * (uint32_t)p.levels);
-        first = level * p.cap;
+        first = level * p.R + (level < p.K ? level : p.K);  // (the long runs come first)
         count = level < p.K ? p.cap : p.R;
         return;
     }

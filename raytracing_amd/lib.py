@@ -242,7 +242,7 @@ class Context:
 
     def render_device(self, cam, params, d_accum_ptr: int):
         """Enqueue a render that ADDS fixed-point sums into device memory at `d_accum_ptr`.  One writer at a time: calls
-        that add to the same buffer must be ordered (one stream, or synchronised) -- from about fifty samples per pixel
+        that add to the same buffer must be ordered (one stream, or synchronised) -- from 32 samples per pixel
         on, a pixel's sums reach memory by a plain load, add and store, not by atomics."""
         self._check(self._L.rt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_accum_ptr)),
                     "rt_render_device")
