@@ -452,10 +452,13 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
         md.ax = m.albedo[0];
         md.ay = m.albedo[1];
         md.az = m.albedo[2];
-        if (m.kind == RT_MAT_LAMBERTIAN && m.texture >= 0 && sc->textures[m.texture].kind == RT_TEX_SOLID) {
+        // A solid colour is carried by the material itself: no texture is looked up for it (tex = MAT_TEX_SOLID)
+        if ((m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC) && m.texture >= 0 &&
+            sc->textures[m.texture].kind == RT_TEX_SOLID) {
             md.ax = sc->textures[m.texture].p[0];
             md.ay = sc->textures[m.texture].p[1];
             md.az = sc->textures[m.texture].p[2];
+            md.tex = MAT_TEX_SOLID;
         }
         // A dielectric has no albedo (its attenuation is white, B1/material.h:59); the slot carries 1.0 / ir, the
         // refraction ratio of a front-face hit (B1/material.h:60), so that no lane divides for it
@@ -1041,6 +1044,15 @@ static int upload_graph(rt_context* ctx, const rt_scene_desc* sc, const GraphChe
     if ((rc = to_device(ctx, chk.top_of, &G.top_of)) != RT_OK) return rc;
     if ((rc = to_device(ctx, extra, &G.extra)) != RT_OK) return rc;
     if ((rc = to_device(ctx, mats, &G.materials)) != RT_OK) return rc;
+    {
+        std::vector<MaterialDev> node_mats(nodes.size(), MaterialDev{RT_MAT_DIFFUSE_LIGHT, -1, 0, 0, 0, 0});
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const int kind = nodes[i].kind;
+            const bool carries = (kind >= RT_NODE_SPHERE && kind <= RT_NODE_YZ_RECT) || kind == RT_NODE_MEDIUM;
+            if (carries && nodes[i].a >= 0 && nodes[i].a < sc->n_materials) node_mats[i] = mats[(size_t)nodes[i].a];
+        }
+        if ((rc = to_device(ctx, node_mats, &G.node_materials)) != RT_OK) return rc;
+    }
     if ((rc = to_device(ctx, texs, &G.textures)) != RT_OK) return rc;
     if ((rc = to_device(ctx, perlins, &G.perlins)) != RT_OK) return rc;
     if ((rc = to_device(ctx, images, &G.images)) != RT_OK) return rc;

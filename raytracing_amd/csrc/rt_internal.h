@@ -34,10 +34,12 @@ struct SphereMotion {
 };
 struct MaterialDev {
     int32_t kind;  // RT_MAT_*
-    int32_t tex;   // texture index of lambertian / diffuse_light / isotropic (general scenes), else -1
-    double ax, ay, az;  // albedo (lambertian with a solid texture, metal); dielectric: ax = 1.0 / ir, ay and az = Schlick's r0 for the ratios 1 / ir and ir
+    int32_t tex;   // texture index of lambertian / diffuse_light / isotropic (general scenes); MAT_TEX_SOLID: the colour is in ax, ay, az; else -1
+    double ax, ay, az;  // albedo (a solid texture's colour, metal); dielectric: ax = 1.0 / ir, ay and az = Schlick's r0 for the ratios 1 / ir and ir
     double param;       // fuzz / ir
 };
+
+constexpr int32_t MAT_TEX_SOLID = -2;
 
 constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS
@@ -282,6 +284,7 @@ struct SceneDev {
     int32_t n_tops;
     const double* extra;
     const MaterialDev* materials;
+    const MaterialDev* node_materials;  // materials[nodes[i].a] per node i: the hit's material without waiting for its node
     const TextureDev* textures;
     const rt_perlin* perlins;
     const ImageDev* images;

@@ -60,6 +60,10 @@ enum : int {
 };
 static_assert(CAND_CAP * 32 + ROW_WORDS * 64 <= STACK_CAP * 64, "the candidate lists of a leaf set use the stack's memory (a set is evaluated while the stack is empty)");
 constexpr double T_MIN = 0.001;      // B2/RayTracing.cpp:25
+// In the variants whose worlds are walked by the wave as a whole (no per-lane stack), Hit::xf names the world's object
+// the hit lies in (an index into SceneDev::tops; -1 when no instance stands above it) instead of the innermost instance node.
+template <int F>
+constexpr bool TOP_CONTEXT = (F & F_XF) != 0 && (F & F_STACK) == 0;
 
 struct Ray {
     d3 o, d;
@@ -324,12 +328,25 @@ __device__ __forceinline__ void medium_hit(const SceneDev& S, const SceneNode& n
 // debug build: per-lane counters of the traversal loop, summed and printed by the render kernel
 static __device__ unsigned long long g_probe_total[16];  // [kind] entries, [12] trips, [13] lane-trips, [14] traces
 // wave cycles per section of the render loop
-enum { PS_REFILL = 0, PS_TOP_PRIM, PS_TOP_BOX, PS_TOP_MEDIUM, PS_SET_SPHERES, PS_SET_BOXES, PS_STACK_WALK, PS_SHADE, PS_COUNT };
+enum { PS_REFILL = 0, PS_TOP_PRIM, PS_TOP_BOX, PS_TOP_MEDIUM, PS_SET_SPHERES, PS_SET_BOXES, PS_STACK_WALK, PS_SURFACE, PS_RANDOM, PS_TEXTURE, PS_SHADE, PS_COUNT };
 static __device__ unsigned long long g_probe_cycles[PS_COUNT];
 static __device__ unsigned long long g_probe_mine[2][6];  // visits of a leaf set by the lanes that reached it: 1-4, 5-8, 9-16, 17-32, 33-64; [5] = lanes
-#define PROBE_MARK(k) do { const unsigned long long now_ = clock64(); if (lane == 0) atomicAdd(&g_probe_cycles[k], now_ - probe_t); probe_t = now_; } while (0)
+// The cycles are summed per wave in registers and added to the device-wide counters once, when the wave ends: an
+// atomic per section and trip from thousands of waves to one address takes longer than the sections themselves and
+// lands in whichever section waits for memory next.  -DRT_SCENE_PROBE=2 adds the event counts (atomics: small frames).
+struct ProbeAcc {
+    unsigned long long cycles[PS_COUNT];
+    unsigned long long t;
+};
+#define PROBE_PARAM , ProbeAcc& probe
+#define PROBE_PASS , probe
+#define PROBE_MARK(k) do { const unsigned long long now_ = clock64(); probe.cycles[k] += now_ - probe.t; probe.t = now_; } while (0)
+#define PROBE_COUNTS (RT_SCENE_PROBE + 0 >= 2)
 #else
+#define PROBE_PARAM
+#define PROBE_PASS
 #define PROBE_MARK(k) do { } while (0)
+#define PROBE_COUNTS 0
 #endif
 // bvh_node::hit (B2/bvh.h:97-106) over the subtree of leaf set `set_index`, without the recursion: its nodes in
 // depth-first order, a node whose box test fails left by its skip link.  For the rays the flat form is not for.  Out of
@@ -369,16 +386,16 @@ __device__ __noinline__ Hit replay_subtree(const LeafSetDev* sets, const int32_t
 
 template <int F>
 __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool on, bool exact_only, uint32_t* stack,
-                                     int lane, const RngCtx& g) {
+                                     int lane, const RngCtx& g PROBE_PARAM) {
 #ifdef RT_SCENE_PROBE
-    unsigned long long probe_t = clock64();
+    probe.t = clock64();
 #endif
     Hit h{__builtin_inf(), -1, -1};
     Ray cur = w;
     int cur_xf = -1;
     d3 inv{1.0f / cur.d.x, 1.0f / cur.d.y, 1.0f / cur.d.z};
     double a = len2(cur.d);
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
     if (lane == 0) atomicAdd(&g_probe_total[14], 1ull);
 #endif
     // The world (a list, checked at upload) is walked by the wave as a whole: all lanes enter its k-th object
@@ -412,6 +429,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     loc_xf = tops[top].chain[i];
                 }
             }
+            const int ctx = TOP_CONTEXT<F> ? (chain > 0 ? top : -1) : loc_xf;  // what Hit::xf records
             SceneNode n;
             n.kind = kind;
             n.a = tops[top].end.a;
@@ -424,7 +442,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                 if (on && prim_hit<F>(S, n, loc, len2(loc.d), tm, T_MIN, h.t, t)) {
                     h.t = t;
                     h.node = node;
-                    h.xf = loc_xf;
+                    h.xf = ctx;
                 }
                 PROBE_MARK(PS_TOP_PRIM);
             } else if (box6) {
@@ -432,13 +450,13 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     const int side = on ? hit_box6(n.p, loc, T_MIN, h.t) : -1;
                     if (side >= 0) {
                         h.node = n.c + side;
-                        h.xf = loc_xf;
+                        h.xf = ctx;
                     }
                 }
                 PROBE_MARK(PS_TOP_BOX);
             } else if (medium) {
                 if constexpr ((F & F_MEDIUM) != 0) {
-                    if (on) medium_hit<F>(S, n, node, loc, loc_xf, tm, g, h);
+                    if (on) medium_hit<F>(S, n, node, loc, ctx, tm, g, h);
                 }
                 PROBE_MARK(PS_TOP_MEDIUM);
             } else {
@@ -465,7 +483,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                     }
                     if (ballot(mine) != 0ull) {
                         const LeafSetDev set = S.sets[n.a];
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
                         const int np = __popcll(ballot(mine));
                         if (lane == 0) {
                             const int kind_of_set = set.spheres.n > 0 ? 0 : 1;
@@ -485,7 +503,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                             const SetHit sh = closest_hit_with(set.spheres, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane, overflowed, clk,
                                                                [&](int j, SetHit& best) {
                                 // (the set's own copies of centre and radius: no walk from the node list to the node)
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
                                 atomicAdd(&g_probe_total[1], 1ull);  // double-precision sphere tests of leaf sets
 #endif
                                 const SphereExact se = set.spheres.exact[j];
@@ -497,7 +515,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                     best.aux = id;
                                 }
                             }, [&](int j, d3 ro, d3 rd, double t_max, double, double& t) -> int {  // the same for a ray of another lane
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
                                 atomicAdd(&g_probe_total[1], 1ull);
 #endif
                                 const SphereExact se = set.spheres.exact[j];
@@ -509,7 +527,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 winner = sh.aux;
                                 sphere_j = sh.id;
                             }
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
                             if (overflowed) atomicAdd(&g_probe_total[15], 1ull);  // rays with more candidates than slots
 #endif
                             PROBE_MARK(PS_SET_SPHERES);
@@ -519,7 +537,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                                 const int first_box = first_slot + set.spheres.n;
                                 const SetHit bh = closest_box_hit(set.boxes, loc.o, loc.d, best_t, mine, exact_only, list, rows, lane,
                                                                   [&](int j, d3 ro, d3 rd, double t_max, double& t) -> int {
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
                                     atomicAdd(&g_probe_total[6], 1ull);  // double-precision box tests of leaf sets
 #endif
                                     const BoxExact be = set.boxes.exact[j];
@@ -544,7 +562,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
                         if (mine && winner >= 0) {
                             h.t = best_t;
                             h.node = winner;
-                            h.xf = loc_xf;
+                            h.xf = ctx;
                         }
                     }
                 }
@@ -557,7 +575,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
     if (on) stack[(sp++) * 64 + lane] = (uint32_t)top_node;
 
     while (ballot(sp > 0) != 0ull) {
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
         if (lane == 0) {
             atomicAdd(&g_probe_total[12], 1ull);
             atomicAdd(&g_probe_total[13], (unsigned long long)__popcll(ballot(sp > 0)));
@@ -580,7 +598,7 @@ __device__ __forceinline__ Hit trace(const SceneDev& S, Ray w, double tm, bool o
             }
             const SceneNode n = S.nodes[e];
             const int kind = n.kind;
-#ifdef RT_SCENE_PROBE
+#if PROBE_COUNTS
             atomicAdd(&g_probe_total[kind < 12 ? kind : 0], 1ull);
 #endif
             if (kind == RT_NODE_BVH) {
@@ -643,6 +661,27 @@ __device__ __forceinline__ void set_face_normal(Surface& s, const Ray& r, d3 out
     s.normal = s.front_face ? outward_normal : -outward_normal;
 }
 
+// The hit record on its way out of instance node xn, whose child saw the ray `child_ray` (B2/hittable.h:48-49, 127-137;
+// a flip_face node turns front_face over and leaves the rest).
+template <int F>
+__device__ __forceinline__ void leave_instance(Surface& s, const SceneNode& xn, const Ray& child_ray) {
+    if ((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE) {
+        s.front_face = !s.front_face;
+    } else if (xn.kind == RT_NODE_TRANSLATE) {
+        s.p = s.p + d3{xn.p[0], xn.p[1], xn.p[2]};
+        set_face_normal(s, child_ray, s.normal);
+    } else {
+        const double sin_theta = xn.p[0], cos_theta = xn.p[1];
+        d3 p = s.p, normal = s.normal;
+        p.x = cos_theta * s.p.x + sin_theta * s.p.z;
+        p.z = -sin_theta * s.p.x + cos_theta * s.p.z;
+        normal.x = cos_theta * s.normal.x + sin_theta * s.normal.z;
+        normal.z = -sin_theta * s.normal.x + cos_theta * s.normal.z;
+        s.p = p;
+        set_face_normal(s, child_ray, normal);
+    }
+}
+
 template <int F>
 __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h, Ray w, double tm) {
     Surface s;
@@ -650,7 +689,36 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
     s.sphere_uv = false;
     s.outward = d3{0, 0, 0};
     const SceneNode n = S.nodes[h.node];
-    const Ray local = ray_in<F>(S, h.xf, w);
+    // Variants without the per-lane stack: h.xf is the index of the world's object the hit lies in, and that object's
+    // entry holds the instance chain above it -- kinds and parameters of up to two levels come back together with the
+    // node in one round of loads, instead of a walk from parent to parent with a node load per level.
+    int xf = h.xf, chain_len = 0;
+    SceneNode lv0, lv1;
+    lv0.kind = lv1.kind = RT_NODE_TRANSLATE;
+    bool by_entry = false;
+    if constexpr (TOP_CONTEXT<F>) {
+        by_entry = true;
+        if (h.xf >= 0) {  // (-1: an object with no instance above it)
+            const TopEntry* te = S.tops + h.xf;
+            chain_len = te->chain_len;
+            lv0.kind = te->chain_kind[0];
+            lv1.kind = te->chain_kind[1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lv0.p[k] = te->chain_p[0][k];
+                lv1.p[k] = te->chain_p[1][k];
+            }
+            by_entry = chain_len <= 2;
+            if (!by_entry) xf = te->chain[chain_len - 1];  // deeper chains: the walk from the innermost instance outwards
+        }
+    }
+    Ray local = w;
+    if (by_entry) {
+        if (chain_len > 0 && !((F & F_FLIP) != 0 && lv0.kind == RT_NODE_FLIP_FACE)) local = xf_apply(lv0, local);
+        if (chain_len > 1 && !((F & F_FLIP) != 0 && lv1.kind == RT_NODE_FLIP_FACE)) local = xf_apply(lv1, local);
+    } else {
+        local = ray_in<F>(S, xf, w);
+    }
     s.p = local.o + h.t * local.d;
     s.mat = n.a;
     switch (n.kind) {
@@ -683,24 +751,15 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
         break;
     }
     // back out through the enclosing instances, innermost first (B2/hittable.h:48-49, 127-137)
-    if constexpr ((F & F_XF) != 0)
-    for (int x = h.xf, lvl = 0; x >= 0 && lvl < XF_DEPTH_CAP; x = S.parent_xf[x], ++lvl) {
-        const SceneNode xn = S.nodes[x];
-        const Ray child_ray = ray_in<F>(S, x, w);
-        if ((F & F_FLIP) != 0 && xn.kind == RT_NODE_FLIP_FACE) {
-            s.front_face = !s.front_face;
-        } else if (xn.kind == RT_NODE_TRANSLATE) {
-            s.p = s.p + d3{xn.p[0], xn.p[1], xn.p[2]};
-            set_face_normal(s, child_ray, s.normal);
+    if constexpr ((F & F_XF) != 0) {
+        if (by_entry) {
+            // the ray inside level 0 once more (level 1's is `local`): a few products, no register held across the switch
+            Ray in0 = w;
+            if (chain_len > 0 && !((F & F_FLIP) != 0 && lv0.kind == RT_NODE_FLIP_FACE)) in0 = xf_apply(lv0, in0);
+            if (chain_len > 1) leave_instance<F>(s, lv1, local);
+            if (chain_len > 0) leave_instance<F>(s, lv0, in0);
         } else {
-            const double sin_theta = xn.p[0], cos_theta = xn.p[1];
-            d3 p = s.p, normal = s.normal;
-            p.x = cos_theta * s.p.x + sin_theta * s.p.z;
-            p.z = -sin_theta * s.p.x + cos_theta * s.p.z;
-            normal.x = cos_theta * s.normal.x + sin_theta * s.normal.z;
-            normal.z = -sin_theta * s.normal.x + cos_theta * s.normal.z;
-            s.p = p;
-            set_face_normal(s, child_ray, normal);
+            for (int x = xf, lvl = 0; x >= 0 && lvl < XF_DEPTH_CAP; x = S.parent_xf[x], ++lvl) leave_instance<F>(s, S.nodes[x], ray_in<F>(S, x, w));
         }
     }
     return s;
@@ -999,7 +1058,8 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
     uint32_t n_bad = 0;                  // per lane
 
 #ifdef RT_SCENE_PROBE
-    unsigned long long probe_t = clock64();
+    ProbeAcc probe{};
+    probe.t = clock64();
 #endif
     for (;;) {
         if (!refill_work(Q, plan, A.sample_begin, lane, active, w, wq)) break;
@@ -1031,7 +1091,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
             pk[5 * 64] = __longlong_as_double((long long)w.fz);
         }
 #endif
-        const Hit h = trace<F>(S, r, tm, on, A.exact_only != 0, stack, lane, g);
+        const Hit h = trace<F>(S, r, tm, on, A.exact_only != 0, stack, lane, g PROBE_PASS);
 #if RT_PARK_PATH_STATE
         if constexpr (PARK) {
             volatile double* pk = s_park[threadIdx.x >> 6][0] + lane;
@@ -1042,7 +1102,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         }
 #endif
 #ifdef RT_SCENE_PROBE
-        probe_t = clock64();  // trace() accounts for its own sections
+        probe.t = clock64();  // trace() accounts for its own sections
 #endif
 
         // the hit record and the material of the lanes that hit something; then, for all lanes together, the first Philox
@@ -1053,16 +1113,18 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         Surface s{};
         MaterialDev m{RT_MAT_DIFFUSE_LIGHT, -1, 0, 0, 0, 0};
         if (hit) {
+            m = S.node_materials[h.node];
             s = make_surface<F>(S, h, r, tm);
-            m = S.materials[s.mat];
         }
+        PROBE_MARK(PS_SURFACE);
         const bool wants_sphere = hit && ((!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
                                           (!importance && m.kind == RT_MAT_ISOTROPIC));
         const u32x4 block0 = philox4x32_10(g.pixel, g.sample, g.site, 0u, A.key0, A.key1);
         const d3 rs = random_in_unit_sphere_for_lanes<SCENE_WAVE_BLOCKS>(wants_sphere, block0, g.pixel, g.sample, g.site, A.key0, A.key1, lane, nullptr);
+        PROBE_MARK(PS_RANDOM);
         // texture::value once, for whichever material wants it (one copy of the Perlin / image / checker code); the
         // turbulence of the lanes that met a noise texture is computed by the whole wave
-        const bool wants_texture = hit && (m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
+        const bool wants_texture = hit && m.tex != MAT_TEX_SOLID && (m.kind == RT_MAT_LAMBERTIAN || ((F & F_MEDIUM) != 0 && !importance && m.kind == RT_MAT_ISOTROPIC) ||
                                            (m.kind == RT_MAT_DIFFUSE_LIGHT && (!importance || s.front_face)));
         int tex_index = -1;
         double turb = 0.0;
@@ -1077,6 +1139,7 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
             }
             turb = perlin_turb_for_lanes(S, noise, perlin_index, s.p, lane);
         }
+        PROBE_MARK(PS_TEXTURE);
         n_rays += (uint32_t)__popcll(ballot(on));
         if (on) {
             bool done = false;
@@ -1093,8 +1156,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
             } else {
                 d3 attenuation{m.ax, m.ay, m.az};
                 d3 nd{0, 0, 0};
-                d3 tex{0, 0, 0};
+                d3 tex{m.ax, m.ay, m.az};  // a solid colour; any other texture is looked up
                 if (wants_texture) tex = texture_value<F>(S, tex_index, s, turb);
+                else if (m.tex != MAT_TEX_SOLID) tex = d3{0, 0, 0};
                 if (importance && m.kind == RT_MAT_LAMBERTIAN) {  // book 3: mixture of light and cosine densities
                     attenuation = importance_bounce(S, s.p, s.normal, tex, g, block0, nd);
                 } else if (importance && m.kind != RT_MAT_METAL && m.kind != RT_MAT_DIELECTRIC) {
@@ -1144,6 +1208,10 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         PROBE_MARK(PS_SHADE);
     }
 
+#ifdef RT_SCENE_PROBE
+    if (lane == 0)
+        for (int k = 0; k < PS_COUNT; ++k) atomicAdd(&g_probe_cycles[k], probe.cycles[k]);
+#endif
     uint64_t v0 = n_samples, v1 = n_rays, v2 = n_bad;  // v0, v1: already the wave's totals
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v2 += __shfl_xor(v2, off);
@@ -1176,7 +1244,10 @@ __global__ void __launch_bounds__(256) k_first_hit_scene(const SceneFirstHitArgs
     const d3 ver{C.vertical[0], C.vertical[1], C.vertical[2]};
     const Ray r{origin + offset, llc + s * hor + t * ver - origin - offset};
     const RngCtx g{pc, 0u, 1u, 0u, 0u};
-    const Hit h = trace<F_EVERY>(A.scene, r, C.time0, on, A.exact_only != 0, stack, lane, g);
+#ifdef RT_SCENE_PROBE
+    ProbeAcc probe{};
+#endif
+    const Hit h = trace<F_EVERY>(A.scene, r, C.time0, on, A.exact_only != 0, stack, lane, g PROBE_PASS);
     if (on) A.ids[pixel] = h.node < 0 ? -1 : A.scene.top_of[h.node];
 }
 
@@ -1259,20 +1330,21 @@ void scene_probe_dump() {
     unsigned long long h[16];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_total), sizeof(h)) != hipSuccess) return;
     static const char* names[] = {"other", "sphere", "moving", "xy", "xz", "yz", "box", "list", "bvh", "translate", "rotate", "medium"};
-    if (h[14] == 0) return;  // nothing rendered since the last dump
-    std::fprintf(stderr, "scene probe: sphere-set rays with more candidates than slots: %llu\n", h[15]);
-    std::fprintf(stderr, "scene probe: wave-traces %llu; stack loop: trips %llu (%.1f per trace), lane fill %.3f\n", h[14], h[12],
-                 (double)h[12] / (double)h[14], h[12] ? (double)h[13] / (64.0 * (double)h[12]) : 0.0);
+    unsigned long long c[PS_COUNT];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_probe_cycles), sizeof(c)) != hipSuccess) return;
+    unsigned long long total = 0;
+    for (int k = 0; k < PS_COUNT; ++k) total += c[k];
+    if (total == 0) return;  // nothing rendered since the last dump
+    if (PROBE_COUNTS) std::fprintf(stderr, "scene probe: sphere-set rays with more candidates than slots: %llu\n", h[15]);
+    if (PROBE_COUNTS) std::fprintf(stderr, "scene probe: wave-traces %llu; stack loop: trips %llu (%.1f per trace), lane fill %.3f\n", h[14], h[12],
+                 (double)h[12] / (double)(h[14] ? h[14] : 1), h[12] ? (double)h[13] / (64.0 * (double)h[12]) : 0.0);
     for (int k = 0; k < 12; ++k)
         if (h[k]) std::fprintf(stderr, "  stack entries %-9s %12llu  (%.2f per lane-trip)\n", names[k], h[k], (double)h[k] / (double)(h[13] ? h[13] : 1));
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_total), z, sizeof(z));
-    unsigned long long c[PS_COUNT];
-    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_probe_cycles), sizeof(c)) != hipSuccess) return;
     static const char* sections[] = {"refill + camera", "top-level primitives", "top-level boxes", "top-level media", "leaf sets: spheres",
-                                     "leaf sets: boxes", "stack walk", "shade"};
-    unsigned long long total = 0;
-    for (int k = 0; k < PS_COUNT; ++k) total += c[k];
+                                     "leaf sets: boxes", "stack walk", "hit record + material", "first block + sphere", "texture lookup + noise",
+                                     "materials + sample end"};
     for (int k = 0; k < PS_COUNT; ++k)
         std::fprintf(stderr, "  wave cycles %-22s %14llu  %5.1f %%\n", sections[k], c[k], 100.0 * (double)c[k] / (double)(total ? total : 1));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cycles), z, sizeof(c));
