@@ -784,16 +784,18 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
     for (int i = 0; i < n; ++i) {
         const rt_node& nd = sc->nodes[prims[(size_t)i]];
         const double radius = nd.kind == RT_NODE_MOVING_SPHERE ? nd.p[8] : nd.p[3];
-        shade_of[(size_t)i] = SphereShade{1.0 / radius, nd.material, 0};
+        shade_of[(size_t)i] = SphereShade{1.0 / radius, sc->materials[nd.material].kind, 0};
     }
-    std::vector<MaterialDev> mats = device_materials(sc);
+    std::vector<MaterialDev> by_index = device_materials(sc);
     // the sphere kernels read a solid albedo from the material itself; tex stays only where a checker must be evaluated
     for (int i = 0; i < sc->n_materials; ++i) {
         const rt_material& m = sc->materials[i];
         const bool checker = timed && m.kind == RT_MAT_LAMBERTIAN && m.texture >= 0 && m.texture < sc->n_textures &&
                              sc->textures[m.texture].kind == RT_TEX_CHECKER;
-        if (!checker) mats[(size_t)i].tex = -1;
+        if (!checker) by_index[(size_t)i].tex = -1;
     }
+    std::vector<MaterialDev> mats((size_t)std::max(1, n));  // one per sphere
+    for (int i = 0; i < n; ++i) mats[(size_t)i] = by_index[(size_t)sc->nodes[prims[(size_t)i]].material];
 
     SphereListDev& S = ctx->spheres;
     S = SphereListDev{};

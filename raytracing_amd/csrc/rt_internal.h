@@ -121,13 +121,13 @@ struct LeafSetDev {
 // What shading a hit on sphere j needs beyond its SphereExact record, in one 16-byte load.
 struct SphereShade {
     double inv_radius;  // 1.0 / radius: the factor of (p - center) / radius, B1/sphere.h:46, B1/vec3.h:96-98
-    int32_t material;
+    int32_t material_kind;  // RT_MAT_* of its material, known one load earlier than the material itself
     int32_t pad;
 };
 struct SphereListDev {
     SphereSetDev set;
     const SphereShade* shade_of;
-    const MaterialDev* materials;
+    const MaterialDev* materials;  // per sphere (a copy of its material): a hit's record and material come back together
     int32_t sky_mode;
     double background[3];
     // book-2 sphere worlds only (null for a book-1 list)

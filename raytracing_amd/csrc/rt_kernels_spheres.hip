@@ -186,15 +186,11 @@ __global__ void __launch_bounds__(RT_SPHERES_WG, TIMED ? RT_MIN_WAVES_TIMED : RT
         // Every material's first draw is block 0 of the segment's site.  Book-1 kernel: the block and the unit-sphere
         // rejection loop of lambertian and metal run at wave level, the loop's further blocks computed by the whole wave
         // for the lanes still in it (only two words per lane stay live across it).
-        int mat = 0;
         u32x4 block0{0, 0, 0, 0};
         d3 rs{0, 0, 0};
         if constexpr (WAVE_BLOCKS) {
             int mat_kind = RT_MAT_DIELECTRIC;
-            if (hit) {
-                mat = S.shade_of[h.id].material;
-                mat_kind = S.materials[mat].kind;
-            }
+            if (hit) mat_kind = S.shade_of[h.id].material_kind;
             const bool wants_sphere = hit && (mat_kind == RT_MAT_LAMBERTIAN || mat_kind == RT_MAT_METAL);
             block0 = philox4x32_10(w.pixel, (uint32_t)w.s_cur, site, 0u, A.key0, A.key1);
             rs = random_in_unit_sphere_for_lanes(wants_sphere, block0, w.pixel, (uint32_t)w.s_cur, site, A.key0, A.key1, lane, nullptr);
@@ -211,10 +207,8 @@ __global__ void __launch_bounds__(RT_SPHERES_WG, TIMED ? RT_MIN_WAVES_TIMED : RT
             double inv_radius = 1.0;
             if (hit) {
                 e = S.set.exact[h.id];
-                const SphereShade sh = S.shade_of[h.id];
-                inv_radius = sh.inv_radius;
-                if constexpr (!WAVE_BLOCKS) mat = sh.material;
-                m = S.materials[mat];
+                inv_radius = S.shade_of[h.id].inv_radius;
+                m = S.materials[h.id];
             }
             // unit_vector(r.direction()) is wanted by the sky, by metal and by dielectric: one copy of the square
             // root and division for all of them instead of one per divergent branch
