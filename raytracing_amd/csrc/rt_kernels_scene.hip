@@ -977,18 +977,37 @@ __device__ __forceinline__ d3 shape_random(const SceneNode& n, d3 origin, uint32
 // ph = Philox block 0 of the site.
 __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 normal, d3 attenuation, const RngCtx& g, u32x4 ph, d3& dir) {
     const Onb uvw = onb_from_w(normal);
-    if (u01(ph.x) < 0.5) {
+    // Three ways to a direction -- towards a rectangle (a point on it), towards a sphere (random_to_sphere in the basis of
+    // the direction to its centre), by the cosine density (random_cosine_direction in the basis of the normal) -- and
+    // the last two are the same arithmetic on different inputs: z from one square root, the angle from one sincos, the
+    // disc radius from one more square root, onb::local.  The lanes of both take that path together, each on its own
+    // inputs, instead of one after the other (the expressions per lane are those of shape_random and of the book's
+    // random_cosine_direction, unchanged).
+    const bool to_light = u01(ph.x) < 0.5;
+    bool to_sphere = false;
+    Onb basis = uvw;
+    const double r1 = u01(ph.z), r2 = u01(ph.w);
+    double inner = 1 - r2;
+    if (to_light) {
         const int idx = (int)u_range(ph.y, 0, (S.n_lights - 1) + 1);
-        dir = shape_random(S.nodes[S.lights[idx < MAX_LIGHT_SHAPES ? idx : 0]], p, ph.z, ph.w);
-    } else {  // random_cosine_direction
-        const double r1 = u01(ph.z), r2 = u01(ph.w);
-        const double z = sqrt(1 - r2);
+        const SceneNode n = S.nodes[S.lights[idx < MAX_LIGHT_SHAPES ? idx : 0]];
+        if (n.kind == RT_NODE_XZ_RECT) {
+            dir = shape_random(n, p, ph.z, ph.w);
+        } else {
+            to_sphere = true;
+            const d3 direction = d3{n.p[0], n.p[1], n.p[2]} - p;
+            basis = onb_from_w(direction);
+            inner = 1 - n.p[3] * n.p[3] / len2(direction);
+        }
+    }
+    if (!to_light || to_sphere) {
+        const double q = sqrt(inner);
+        const double z = to_sphere ? 1 + r2 * (q - 1) : q;
         const double phi = 2 * PI_D * r1;
-        double sin_phi, cos_phi;
-        sincos(phi, &sin_phi, &cos_phi);
-        const double x = cos_phi * sqrt(r2);
-        const double y = sin_phi * sqrt(r2);
-        dir = onb_local(uvw, d3{x, y, z});
+        double sin_phi, cos_phi;  // one argument reduction for both; the device library's sincos returns what its sin and cos
+        sincos(phi, &sin_phi, &cos_phi);  // return (compared over 1.3e8 rays of config 5: not one sum differs)
+        const double s = sqrt(to_sphere ? 1 - z * z : r2);
+        dir = onb_local(basis, d3{cos_phi * s, sin_phi * s, z});
     }
     const d3 ud = unit_vector(dir);
     const double cosine_w = dot(ud, uvw.w);
