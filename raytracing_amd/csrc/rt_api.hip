@@ -460,6 +460,24 @@ static std::vector<MaterialDev> device_materials(const rt_scene_desc* sc) {
             md.az = sc->textures[m.texture].p[2];
             md.tex = MAT_TEX_SOLID;
         }
+        if (md.tex >= 0) {  // does texture::value of this material ever read u, v?  (an image, possibly behind checkers)
+            std::vector<int> todo{md.tex};
+            bool image = false;
+            for (int level = 0; level < 5 && !todo.empty(); ++level) {
+                std::vector<int> next;
+                for (int t : todo) {
+                    if (t < 0 || t >= sc->n_textures) continue;
+                    const rt_texture& tx = sc->textures[t];
+                    if (tx.kind == RT_TEX_IMAGE) image = true;
+                    if (tx.kind == RT_TEX_CHECKER) {
+                        next.push_back(tx.a);
+                        next.push_back(tx.b);
+                    }
+                }
+                todo.swap(next);
+            }
+            if (image) md.tex |= MAT_TEX_WANTS_UV;
+        }
         // A dielectric has no albedo (its attenuation is white, B1/material.h:59); the slot carries 1.0 / ir, the
         // refraction ratio of a front-face hit (B1/material.h:60), so that no lane divides for it
         // and ay, az Schlick's r0 = ((1 - x) / (1 + x))^2 (B1/material.h:85-86) for the two ratios a ray can meet,
@@ -793,6 +811,7 @@ static int upload_sphere_list(rt_context* ctx, const rt_scene_desc* sc, const st
         const bool checker = timed && m.kind == RT_MAT_LAMBERTIAN && m.texture >= 0 && m.texture < sc->n_textures &&
                              sc->textures[m.texture].kind == RT_TEX_CHECKER;
         if (!checker) by_index[(size_t)i].tex = -1;
+        else by_index[(size_t)i].tex &= ~MAT_TEX_WANTS_UV;
     }
     std::vector<MaterialDev> mats((size_t)std::max(1, n));  // one per sphere
     for (int i = 0; i < n; ++i) mats[(size_t)i] = by_index[(size_t)sc->nodes[prims[(size_t)i]].material];

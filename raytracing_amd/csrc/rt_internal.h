@@ -40,6 +40,7 @@ struct MaterialDev {
 };
 
 constexpr int32_t MAT_TEX_SOLID = -2;
+constexpr int32_t MAT_TEX_WANTS_UV = 1 << 30;  // set in a texture index whose texture (or a checker's branch) is an image: the only reader of u, v
 
 constexpr int SCREEN_GROUP = 32;  // spheres per screening mask word (16 pairs)
 constexpr int CAND_CAP = 32;      // candidate slots per lane held in LDS

@@ -683,7 +683,7 @@ __device__ __forceinline__ void leave_instance(Surface& s, const SceneNode& xn, 
 }
 
 template <int F>
-__device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h, Ray w, double tm) {
+__device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h, Ray w, double tm, bool wants_uv) {
     Surface s;
     s.u = s.v = 0.0;  // moving_sphere and constant_medium leave u,v untouched in the reference
     s.sphere_uv = false;
@@ -737,10 +737,12 @@ __device__ __forceinline__ Surface make_surface(const SceneDev& S, const Hit& h,
     case RT_NODE_XZ_RECT:
     case RT_NODE_YZ_RECT: {  // B2/aarect.h:36-43
         if constexpr (!(F & F_RECT)) break;
-        double t, ua, vb;
-        hit_rect(n, local, h.t, h.t, t, ua, vb);  // same arithmetic as the accepted test: recovers a, b
-        s.u = (ua - n.p[0]) / (n.p[1] - n.p[0]);
-        s.v = (vb - n.p[2]) / (n.p[3] - n.p[2]);
+        if (wants_uv) {  // (only an image texture reads them)
+            // the rectangle's own coordinates of the hit are those of rec.p = r.at(t): the same sum of the same products
+            const double ua = comp(s.p, n.kind == RT_NODE_YZ_RECT ? 1 : 0), vb = comp(s.p, n.kind == RT_NODE_XY_RECT ? 1 : 2);
+            s.u = (ua - n.p[0]) / (n.p[1] - n.p[0]);
+            s.v = (vb - n.p[2]) / (n.p[3] - n.p[2]);
+        }
         const d3 outward_normal = n.kind == RT_NODE_XY_RECT ? d3{0, 0, 1} : (n.kind == RT_NODE_XZ_RECT ? d3{0, 1, 0} : d3{1, 0, 0});
         set_face_normal(s, local, outward_normal);
         break;
@@ -1133,7 +1135,9 @@ __global__ void __launch_bounds__(256, MIN_WAVES) k_render_scene(const SceneRend
         MaterialDev m{RT_MAT_DIFFUSE_LIGHT, -1, 0, 0, 0, 0};
         if (hit) {
             m = S.node_materials[h.node];
-            s = make_surface<F>(S, h, r, tm);
+            const bool wants_uv = (F & F_IMAGE) != 0 && m.tex >= 0 && (m.tex & MAT_TEX_WANTS_UV) != 0;
+            s = make_surface<F>(S, h, r, tm, wants_uv);
+            if (m.tex >= 0) m.tex &= ~MAT_TEX_WANTS_UV;
         }
         PROBE_MARK(PS_SURFACE);
         const bool wants_sphere = hit && ((!importance && m.kind == RT_MAT_LAMBERTIAN) || m.kind == RT_MAT_METAL ||
