@@ -978,7 +978,10 @@ __device__ __forceinline__ d3 shape_random(const SceneNode& n, d3 origin, uint32
 // cosine density; returns  (1 / pdf_val) * (scattering_pdf * attenuation)  as the factor of the throughput.
 // ph = Philox block 0 of the site.
 __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 normal, d3 attenuation, const RngCtx& g, u32x4 ph, d3& dir) {
-    const Onb uvw = onb_from_w(normal);
+    // (of the normal's basis only w is read by the densities below; the other two axes are completed further down, for
+    // whichever w the lane samples around: onb::build_from_w in two steps)
+    Onb uvw;
+    uvw.w = unit_vector(normal);
     // Three ways to a direction -- towards a rectangle (a point on it), towards a sphere (random_to_sphere in the basis of
     // the direction to its centre), by the cosine density (random_cosine_direction in the basis of the normal) -- and
     // the last two are the same arithmetic on different inputs: z from one square root, the angle from one sincos, the
@@ -987,7 +990,7 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
     // random_cosine_direction, unchanged).
     const bool to_light = u01(ph.x) < 0.5;
     bool to_sphere = false;
-    Onb basis = uvw;
+    d3 axis = uvw.w;
     const double r1 = u01(ph.z), r2 = u01(ph.w);
     double inner = 1 - r2;
     if (to_light) {
@@ -998,7 +1001,7 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
         } else {
             to_sphere = true;
             const d3 direction = d3{n.p[0], n.p[1], n.p[2]} - p;
-            basis = onb_from_w(direction);
+            axis = unit_vector(direction);
             inner = 1 - n.p[3] * n.p[3] / len2(direction);
         }
     }
@@ -1009,6 +1012,11 @@ __device__ __forceinline__ d3 importance_bounce(const SceneDev& S, d3 p, d3 norm
         double sin_phi, cos_phi;  // one argument reduction for both; the device library's sincos returns what its sin and cos
         sincos(phi, &sin_phi, &cos_phi);  // return (compared over 1.3e8 rays of config 5: not one sum differs)
         const double s = sqrt(to_sphere ? 1 - z * z : r2);
+        Onb basis;
+        basis.w = axis;
+        const d3 a = (fabs(axis.x) > 0.9) ? d3{0, 1, 0} : d3{1, 0, 0};
+        basis.v = unit_vector(cross(axis, a));
+        basis.u = cross(axis, basis.v);
         dir = onb_local(basis, d3{cos_phi * s, sin_phi * s, z});
     }
     const d3 ud = unit_vector(dir);
